@@ -1,0 +1,143 @@
+/*
+ * wavtokenizer_amd.h — C-ABI of libwavtok_hip.so (MI355X / gfx950).
+ *
+ * The reference (Rita-zi/WavTokenizer) is 100 % Python; it has no FFI boundary of its own.
+ * The drop-in boundary is the Python class decoder/pretrained.py:32 `WavTokenizer`; this
+ * library is what our same-named class binds (ctypes) underneath.  Each entry point cites the
+ * reference function whose work it performs.  Conventions:
+ *
+ *   - plain C: raw device pointers, explicit sizes, `void* stream` = hipStream_t
+ *     (NULL = the null stream).  No torch types.
+ *   - every function returns 0 on success, a negative wt_status otherwise; nothing throws
+ *     across the ABI; wt_last_error() gives a thread-local message.
+ *   - the caller owns every buffer, including the workspace (size from
+ *     wt_plan_workspace_bytes).  Kernels are enqueued on `stream`; nothing synchronises,
+ *     allocates or frees inside wt_encode / wt_decode / wt_codes_to_features.
+ *   - a wt_model is immutable after creation (folded + packed weights in HBM) and may be shared
+ *     by host threads; a wt_plan is immutable too; concurrent calls need distinct workspaces.
+ *   - activations inside the library are time-major [clip][frame][channel] fp32; the API
+ *     tensors keep the reference's layouts (wav (B,T); features (B,512,L); codes (K,B,L) int64).
+ */
+#ifndef WAVTOKENIZER_AMD_H
+#define WAVTOKENIZER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    WT_OK = 0,
+    WT_ERR_INVALID = -1,      /* bad argument / unsupported configuration */
+    WT_ERR_MISSING_TENSOR = -2,
+    WT_ERR_SHAPE = -3,
+    WT_ERR_HIP = -4,          /* a HIP runtime call failed */
+    WT_ERR_NOT_INITED = -5    /* codebook buffer `inited` != 1 (core_vq.py:140-151 would run k-means) */
+} wt_status;
+
+/* Architecture: the YAML keys decoder/pretrained.py:81-92 (from_hparams0802) reads. */
+typedef struct {
+    int32_t n_ratios;
+    int32_t ratios[8];               /* `dowmsamples`, decoder order as written in the YAML */
+    int32_t vq_bins;                 /* 4096 */
+    int32_t num_quantizers;          /* 1 */
+    int32_t input_channels;          /* 512 */
+    int32_t dim;                     /* 768 */
+    int32_t intermediate_dim;        /* 2304 */
+    int32_t num_layers;              /* 12 */
+    int32_t adanorm_num_embeddings;  /* 4 */
+    int32_t n_fft;                   /* 2400 / 1280 */
+    int32_t hop_length;              /* 600 / 320 */
+    int32_t padding_same;            /* 1 = "same" (the only mode the YAMLs select) */
+} wt_arch;
+
+/* One named fp32 host array of a checkpoint `state_dict` (keys: SURVEY.md Appendix A). */
+typedef struct {
+    const char*  name;
+    const float* data;    /* host pointer, fp32, contiguous */
+    int64_t      numel;
+} wt_tensor;
+
+typedef struct wt_model wt_model;
+typedef struct wt_plan  wt_plan;
+
+typedef enum {
+    WT_PLAN_ENCODE = 0,          /* audio (B,T)       -> features (B,512,L) + codes (1,B,L)  */
+    WT_PLAN_DECODE = 1,          /* features (B,512,L) -> audio (B, L*hop)                     */
+    WT_PLAN_SEANET_DECODER = 2   /* features (B,512,L) -> audio (B,1,L*hop): encodec.decoder   */
+} wt_plan_kind;
+
+enum { WT_PLAN_FLAG_KEEP_STAGES = 1 };  /* never alias stage buffers (debug taps; bigger workspace) */
+
+const char* wt_last_error(void);
+const char* wt_version(void);
+
+/* Replaces: WavTokenizer.from_pretrained0802's load_state_dict (decoder/pretrained.py:95-114)
+ * plus the weight_norm pre-forward hook of every SConv1d (encoder/modules/conv.py:25-34), done
+ * once here: w = g * v / ||v||.  Copies, folds and packs the weights into HBM on `device`. */
+int  wt_model_create(const wt_arch* arch, const wt_tensor* tensors, int32_t n_tensors, int32_t device,
+                     wt_model** out);
+void wt_model_destroy(wt_model* m);
+int  wt_model_hop(const wt_model* m);                 /* prod(ratios) */
+int64_t wt_model_weight_bytes(const wt_model* m);     /* packed fp32 bytes resident in HBM */
+
+/* A plan fixes (kind, B, T or L): kernel launch list + workspace layout.
+ * `len` = T (samples) for WT_PLAN_ENCODE, L (frames) for the two decode kinds. */
+int    wt_plan_create(const wt_model* m, int32_t kind, int32_t B, int64_t len, int32_t flags, wt_plan** out);
+void   wt_plan_destroy(wt_plan* p);
+size_t wt_plan_workspace_bytes(const wt_plan* p);
+int64_t wt_plan_frames(const wt_plan* p);             /* L = ceil(T / hop) (conv.py:54-61) */
+int    wt_plan_num_launches(const wt_plan* p);
+/* Debug taps: byte offset / element count of a named stage buffer inside the workspace. */
+int    wt_plan_find_buffer(const wt_plan* p, const char* name, size_t* offset, size_t* numel);
+int    wt_plan_buffer_name(const wt_plan* p, int32_t index, const char** name);
+
+/* Replaces: WavTokenizer.encode_infer (decoder/pretrained.py:186-189) ->
+ * EncodecFeatures.infer (decoder/feature_extractors.py:131-142): SEANetEncoder
+ * (encoder/modules/seanet.py:143) + ResidualVectorQuantizer.infer (encoder/quantization/vq.py:115-140).
+ *   wav      [B][T] fp32 (device)
+ *   features [B][512][L] fp32 (device, out) — quantized embedding
+ *   codes    [1][B][L] int64 (device, out)
+ *   emb_out  optional [B][512][L] fp32: encoder output before quantisation (may be NULL) */
+int wt_encode(const wt_plan* p, const float* wav, float* features, int64_t* codes, float* emb_out,
+              void* workspace, void* stream);
+
+/* Replaces: WavTokenizer.codes_to_features (decoder/pretrained.py:209-239).
+ *   codes [K][B][L] int64, features [B][512][L] fp32; K <= num_quantizers. */
+int wt_codes_to_features(const wt_model* m, const int64_t* codes, int32_t K, int32_t B, int64_t L,
+                         float* features, void* stream);
+
+/* Replaces: WavTokenizer.decode (decoder/pretrained.py:192-207): VocosBackbone.forward
+ * (decoder/models.py:223-235) + ISTFTHead.forward (decoder/heads.py:42-67) + ISTFT.forward
+ * (decoder/spectral_ops.py:33-75).
+ *   features [B][512][L] fp32, bandwidth_id in [0, adanorm_num_embeddings), wav_out [B][L*hop].
+ *   backbone_out optional [B][L][dim] fp32 (may be NULL). */
+int wt_decode(const wt_plan* p, const float* features, int32_t bandwidth_id, float* wav_out,
+              float* backbone_out, void* workspace, void* stream);
+
+/* Replaces: SEANetDecoder.forward (encoder/modules/seanet.py:236-238), reached by callers as
+ * model.feature_extractor.encodec.decoder(features).  wav_out [B][1][L*hop]. */
+int wt_seanet_decode(const wt_plan* p, const float* features, float* wav_out, void* workspace, void* stream);
+
+/* ---- single-stage entry points (unit parity tests; same kernels the plans launch) ---------- */
+
+/* Replaces: SConv1d.forward with weight-normed Conv1d (encoder/modules/conv.py:195-211), time-major
+ * tensors: x [B][T][Cin] -> y [B][Tout][Cout], w [Cout][k][Cin] (already folded), reflect padding,
+ * optional ELU on the input (seanet.py:49,124,136).  Tout = ceil(T/stride). */
+int wt_sconv1d(const float* x, const float* w, const float* bias, float* y, int32_t B, int64_t T,
+               int32_t Cin, int32_t Cout, int32_t k, int32_t stride, int32_t dilation, int32_t elu_input,
+               void* stream);
+
+/* Replaces: EuclideanCodebook.quantize (encoder/quantization/core_vq.py:175-183): x [N][D] rows,
+ * embed [bins][D]; codes_out [N] int64 = argmax_j -(|x|^2 - 2 x.e_j + |e_j|^2), ties -> lowest j.
+ * workspace: wt_vq_workspace_bytes(N, bins). */
+size_t wt_vq_workspace_bytes(int64_t N, int32_t bins);
+int wt_vq_nearest(const float* x, const float* embed, int64_t N, int32_t D, int32_t bins, int64_t* codes_out,
+                  void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAVTOKENIZER_AMD_H */

@@ -150,7 +150,9 @@ def main():
         sd = synth.make_state_dict(arch, seed=WEIGHT_SEED)
         ref = build_reference(YAMLS[name], sd)
         orc = OracleWavTokenizer(arch, sd)
-        entry = {"arch": arch.to_dict(), "weights": synth.weights_manifest(sd), "cases": {}}
+        entry = {"arch": arch.to_dict(), "weights": synth.weights_manifest(sd), "cases": {},
+                 # the reference module's own state_dict layout (pins wavtokenizer_amd/state_spec.py)
+                 "ref_state_keys": {k: list(v.shape) for k, v in ref.state_dict().items()}}
 
         # -- case A: B=2 x 3 s, everything pinned, stage checkpoints
         wav, seed, m = find_clips(ref, orc, arch, 2, 72000, 1000)

@@ -1,0 +1,298 @@
+"""GPU parity: the HIP path (through the C-ABI, via the drop-in WavTokenizer class) against
+ (a) the golden fixtures written from the real reference and (b) the oracle run on this host.
+
+Bars (north_star): codes bit-exact; waveform within 1e-4 relative.  Stage checkpoints are held
+to 3e-5 relative L2 (fp32 re-association only).  A code mismatch is tolerated only at frames
+whose reference top-2 margin is a near tie (tests/util.py NEAR_TIE_MARGIN) and is reported.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import (WAV_REL_TOL, check_codes, load_case, manifest, rel_l2, synth_state_dict)
+
+pytestmark = pytest.mark.gpu
+
+STAGE_TOL = 3e-5
+BW = torch.tensor([0])
+
+
+def _model(arch_name, with_seanet_decoder=False):
+    from wavtokenizer_amd import WavTokenizer, NAMED_ARCHS, synth
+    arch = NAMED_ARCHS[arch_name]
+    if with_seanet_decoder:
+        sd = synth.make_state_dict(arch, seed=manifest()["weight_seed"], with_seanet_decoder=True)
+    else:
+        sd = synth_state_dict(arch_name)
+    m = WavTokenizer.from_arch(arch)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    return m.eval().to("cuda"), sd
+
+
+@pytest.fixture(scope="module", params=["hop600", "hop320"])
+def gpu_model(request):
+    m, sd = _model(request.param)
+    return request.param, m, sd
+
+
+def _oracle(arch_name, sd):
+    from oracle.cpu_ref import OracleWavTokenizer
+    from wavtokenizer_amd import NAMED_ARCHS
+    return OracleWavTokenizer(NAMED_ARCHS[arch_name], sd)
+
+
+def test_native_library_loaded():
+    from wavtokenizer_amd import _capi
+    assert b"gfx950" in _capi.lib.wt_version()
+    with open("/proc/self/maps") as f:
+        assert "libwavtok_hip.so" in f.read()
+
+
+def test_b2_stage_checkpoints(gpu_model):
+    """Every stage of encode and decode against the reference's captured activations."""
+    from wavtokenizer_amd import _capi
+    name, m, _sd = gpu_model
+    g = load_case(name, "b2_t72000")
+    wav = torch.from_numpy(g["wav_in"]).cuda()
+    m.set_debug_keep_stages(True)
+    try:
+        feats, codes = m.encode_infer(wav, bandwidth_id=BW)
+        out = m.decode(feats, bandwidth_id=BW)
+        torch.cuda.synchronize()
+        B, T = wav.shape
+        L = codes.shape[-1]
+        report = []
+        stages = [k.split("/")[1] for k in g.files if k.startswith("tap/") and k.endswith("/l2")]
+        for st in stages:
+            shape = tuple(g[f"tap/{st}/shape"])
+            if st.startswith("enc."):
+                kind, length = _capi.WT_PLAN_ENCODE, T
+            else:
+                kind, length = _capi.WT_PLAN_DECODE, L
+            if st in ("head.out", "bb.pos_net.5"):
+                continue          # fused into the consumer (spectrum epilogue / AdaLN row pass): never in HBM
+            buf = m.debug_stage(kind, B, length, st)
+            if st == "bb.out":
+                mine = buf.view(shape).cpu().numpy()                 # (B, L, C) in both
+                ref_head, my_head = g[f"tap/{st}/head"], mine[0][:, :16]
+            else:
+                Bc, C, Tt = shape                                    # reference (B, C, T); ours (B, T, C)
+                mine = buf.view(Bc, Tt, C).cpu().numpy()
+                ref_head, my_head = g[f"tap/{st}/head"], mine[0, :16, :].T
+            l2 = float(np.sqrt((mine.astype(np.float64) ** 2).sum()))
+            e_head = rel_l2(my_head, ref_head)
+            e_l2 = abs(l2 - float(g[f"tap/{st}/l2"])) / float(g[f"tap/{st}/l2"])
+            report.append((st, e_head, e_l2))
+        bad = [r for r in report if r[1] > STAGE_TOL or r[2] > STAGE_TOL]
+        assert not bad, "first diverging stage: %s (head rel-L2 %.3g, |L2| rel %.3g); all: %s" % (*bad[0], report)
+    finally:
+        m.set_debug_keep_stages(False)
+    assert check_codes(codes.cpu().numpy(), g["codes"], g["margin"], name) == 0
+    assert codes.dtype == torch.int64 and tuple(codes.shape) == g["codes"].shape
+    assert rel_l2(out.cpu().numpy(), g["wav_out"]) < WAV_REL_TOL
+
+
+def test_b2_outputs(gpu_model):
+    name, m, _sd = gpu_model
+    g = load_case(name, "b2_t72000")
+    wav = torch.from_numpy(g["wav_in"]).cuda()
+    feats, codes = m.encode_infer(wav, bandwidth_id=BW)
+    emb = m.feature_extractor.encodec.encoder(wav.unsqueeze(1))
+    bb = m.backbone(feats, bandwidth_id=BW)
+    out = m.decode(feats, bandwidth_id=BW)
+    assert check_codes(codes.cpu().numpy(), g["codes"], g["margin"], name) == 0
+    assert rel_l2(emb.cpu().numpy(), g["emb"]) < STAGE_TOL
+    assert rel_l2(bb.cpu().numpy(), g["bb_out"]) < STAGE_TOL
+    err = rel_l2(out.cpu().numpy(), g["wav_out"])
+    assert err < WAV_REL_TOL, err
+    # features are exactly the codebook rows of the codes (core_vq.py:188-190)
+    sd_embed = torch.from_numpy(synth_state_dict(name)["feature_extractor.encodec.quantizer.vq.layers.0._codebook.embed"])
+    want = sd_embed[torch.from_numpy(g["codes"])[0]].permute(0, 2, 1)
+    assert torch.equal(feats.cpu(), want)
+    # codes_to_features == dequantise; decode(codes_to_features(codes)) == decode(features) bit for bit
+    f2 = m.codes_to_features(codes)
+    assert torch.equal(f2, feats)
+    assert torch.equal(m.codes_to_features(codes[:, 0]), feats[:1]) or codes.shape[1] != 1
+    assert torch.equal(m.decode(f2, bandwidth_id=BW), out)
+    # forward() = copy-synthesis
+    assert torch.equal(m(wav, bandwidth_id=BW), out)
+    # another bandwidth row changes the output (AdaLayerNorm conditioning is live)
+    assert not torch.equal(m.decode(feats, bandwidth_id=torch.tensor([2])), out)
+
+
+def test_length_not_multiple_of_hop(gpu_model):
+    name, m, _sd = gpu_model
+    g = load_case(name, "b1_t61920")
+    feats, codes = m.encode_infer(torch.from_numpy(g["wav_in"]).cuda(), bandwidth_id=BW)
+    out = m.decode(feats, bandwidth_id=BW)
+    assert tuple(codes.shape) == g["codes"].shape and tuple(out.shape) == g["wav_out"].shape
+    assert check_codes(codes.cpu().numpy(), g["codes"], g["margin"], name) == 0
+    assert rel_l2(out.cpu().numpy(), g["wav_out"]) < WAV_REL_TOL
+
+
+def test_edge_lengths(gpu_model):
+    """T = 1, 5, 599, 600, 601, 1927: short-input reflect padding and ragged last frames."""
+    name, m, _sd = gpu_model
+    g = load_case(name, "edge")
+    for T in manifest()["archs"][name]["cases"]["edge"]["T"]:
+        feats, codes = m.encode_infer(torch.from_numpy(g[f"T{T}/wav_in"]).cuda(), bandwidth_id=BW)
+        out = m.decode(feats, bandwidth_id=BW)
+        assert tuple(codes.shape) == g[f"T{T}/codes"].shape, T
+        flips = check_codes(codes.cpu().numpy(), g[f"T{T}/codes"], g[f"T{T}/margin"], f"{name} T={T}")
+        if flips == 0:
+            assert rel_l2(out.cpu().numpy(), g[f"T{T}/wav_out"]) < WAV_REL_TOL, T
+
+
+def test_30s_clip():
+    """BASELINE config 5 shape: one 30 s clip (L = 1200), hop-600."""
+    m, _sd = _model("hop600")
+    g = load_case("hop600", "b1_t720000")
+    feats, codes = m.encode_infer(torch.from_numpy(g["wav_in"]).cuda(), bandwidth_id=BW)
+    out = m.decode(feats, bandwidth_id=BW).cpu().numpy()
+    assert check_codes(codes.cpu().numpy(), g["codes"], g["margin"], "30s") == 0
+    assert rel_l2(out[:, :4096], g["wav_out_head"]) < WAV_REL_TOL
+    assert rel_l2(out[:, -4096:], g["wav_out_tail"]) < WAV_REL_TOL
+    assert abs(np.sqrt((out.astype(np.float64) ** 2).sum()) - float(g["wav_out_l2"])) < WAV_REL_TOL * float(g["wav_out_l2"])
+
+
+def test_full_batch_against_oracle_and_invariants(gpu_model):
+    """BASELINE config 2/3 size (B = 64 x 3 s): GPU vs the oracle on this host, plus
+    size-independent properties: batch invariance (a clip's result does not depend on its
+    neighbours) and the encode -> codes -> decode round trip."""
+    from wavtokenizer_amd import synth
+    name, m, sd = gpu_model
+    B = 64
+    wav_np = synth.make_clips(B, 72000, seed=7000)
+    wav = torch.from_numpy(wav_np).cuda()
+    feats, codes = m.encode_infer(wav, bandwidth_id=BW)
+    out = m.decode(feats, bandwidth_id=BW)
+    # --- batch invariance, bit for bit
+    f3, c3 = m.encode_infer(wav[5:8].contiguous(), bandwidth_id=BW)
+    assert torch.equal(c3, codes[:, 5:8])
+    assert torch.equal(m.decode(f3, bandwidth_id=BW), out[5:8])
+    # --- round trip through codes
+    assert torch.equal(m.decode(m.codes_to_features(codes), bandwidth_id=BW), out)
+    # --- against the oracle on the host cores
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    orc = _oracle(name, sd)
+    taps = {}
+    with torch.inference_mode():
+        fo, co = orc.encode_infer(torch.from_numpy(wav_np), BW, taps)
+    flips = check_codes(codes.cpu().numpy(), co.numpy(), taps["vq.margin"].numpy(), f"{name} B=64")
+    # decode the ORACLE's features on both sides so near-tie flips cannot leak into the waveform check
+    with torch.inference_mode():
+        wo = orc.decode(fo, BW)
+    wg = m.decode(fo.cuda(), bandwidth_id=BW)
+    err = rel_l2(wg.cpu().numpy(), wo.numpy())
+    per_clip = max(rel_l2(wg[i].cpu().numpy(), wo[i].numpy()) for i in range(B))
+    print(f"[{name}] B=64: near-tie code flips {flips}/{codes.numel()}, waveform rel-L2 {err:.3g} (worst clip {per_clip:.3g})")
+    assert err < WAV_REL_TOL and per_clip < WAV_REL_TOL
+    assert flips <= 4
+
+
+def test_b8_fixture_codes(gpu_model):
+    from wavtokenizer_amd import synth
+    from tests.util import NEAR_TIE_MARGIN
+    import hashlib
+    name, m, _sd = gpu_model
+    case = manifest()["archs"][name]["cases"]["b8_t72000"]
+    wav_np = synth.make_clips(8, 72000, case["clip_seed"])
+    if hashlib.sha256(wav_np.tobytes()).hexdigest() != case["wav_in_sha256"]:
+        pytest.skip("host libm renders the synthetic clips differently from the fixture container")
+    g = load_case(name, "b8_t72000")
+    feats, codes = m.encode_infer(torch.from_numpy(wav_np).cuda(), bandwidth_id=BW)
+    flips = check_codes(codes.cpu().numpy(), g["codes"], g["margin"], name)
+    assert flips <= int((g["margin"] < NEAR_TIE_MARGIN).sum())
+    if flips == 0:
+        out = m.decode(feats, bandwidth_id=BW).cpu().numpy().astype(np.float64)
+        assert np.allclose(np.sqrt((out ** 2).sum(axis=1)), g["wav_out_l2"], rtol=WAV_REL_TOL)
+        assert rel_l2(out[:, :256], g["wav_out_head"]) < 5 * WAV_REL_TOL
+
+
+def test_errors_like_the_reference(gpu_model):
+    name, m, _sd = gpu_model
+    feats = torch.zeros(1, 512, 4, device="cuda")
+    with pytest.raises(AssertionError):
+        m.decode(feats)                     # missing bandwidth_id: decoder/models.py:227
+    from wavtokenizer_amd._capi import WavTokError
+    with pytest.raises(WavTokError):
+        m.decode(feats, bandwidth_id=torch.tensor([7]))
+
+
+# ------------------------------------------------------------------- single-stage entry points
+def _ptr(t):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr())
+
+
+@pytest.mark.parametrize("B,T,Cin,Cout,k,stride,dil,elu", [
+    (2, 1000, 32, 16, 3, 1, 1, 1), (2, 1000, 16, 32, 1, 1, 1, 1), (3, 777, 32, 64, 8, 4, 1, 1),
+    (2, 333, 64, 128, 10, 5, 1, 1), (1, 50, 256, 512, 12, 6, 1, 1), (2, 120, 512, 512, 7, 1, 1, 0),
+    (2, 200, 32, 32, 3, 1, 2, 1), (2, 200, 32, 32, 3, 1, 4, 0), (1, 2, 32, 32, 7, 1, 1, 1), (1, 1, 64, 64, 8, 4, 1, 0),
+    (1, 3, 32, 64, 16, 8, 1, 1),
+])
+def test_sconv1d_kernel(B, T, Cin, Cout, k, stride, dil, elu):
+    """wt_sconv1d (the implicit-GEMM conv) against SConv1d semantics (conv.py:195-211) on CPU,
+    including dilation and inputs shorter than the reflect pad."""
+    import torch.nn.functional as F
+    from oracle.cpu_ref import get_extra_padding_for_conv1d, pad1d_reflect
+    from wavtokenizer_amd._capi import lib, check
+    gen = torch.Generator().manual_seed(B * 1000 + T + k)
+    x = torch.randn(B, Cin, T, generator=gen)
+    w = torch.randn(Cout, Cin, k, generator=gen) / (Cin * k) ** 0.5
+    b = torch.randn(Cout, generator=gen)
+    keff = (k - 1) * dil + 1
+    pt = keff - stride
+    extra = get_extra_padding_for_conv1d(T, keff, stride, pt)
+    pr = pt // 2
+    xin = F.elu(x) if elu else x
+    want = F.conv1d(pad1d_reflect(xin, (pt - pr, pr + extra)), w, b, stride=stride, dilation=dil)
+    Tout = want.shape[-1]
+    xg = x.permute(0, 2, 1).contiguous().cuda()
+    wg = w.permute(0, 2, 1).contiguous().cuda()      # [Cout][k][Cin]
+    bg = b.cuda()
+    y = torch.empty(B, Tout, Cout, device="cuda")
+    check(lib.wt_sconv1d(_ptr(xg), _ptr(wg), _ptr(bg), _ptr(y), B, T, Cin, Cout, k, stride, dil, elu, None), "wt_sconv1d")
+    torch.cuda.synchronize()
+    assert rel_l2(y.permute(0, 2, 1).cpu().numpy(), want.numpy()) < 1e-5
+
+
+def test_vq_nearest_kernel_and_ties():
+    """wt_vq_nearest vs core_vq.py:175-183 on CPU; duplicated codebook rows tie -> lowest index."""
+    from wavtokenizer_amd._capi import lib, check
+    gen = torch.Generator().manual_seed(11)
+    bins, D, N = 4096, 512, 1000
+    embed = torch.randn(bins, D, generator=gen)
+    embed[3000] = embed[17]          # exact duplicates: the tie must resolve to 17
+    embed[4095] = embed[2048]
+    x = torch.randn(N, D, generator=gen) * 0.7
+    x[0] = embed[17]
+    x[1] = embed[2048]
+    x[2] = embed[4095]
+    e = embed.t()
+    dist = -(x.pow(2).sum(1, keepdim=True) - 2 * x @ e + e.pow(2).sum(0, keepdim=True))
+    want = dist.max(dim=-1).indices
+    top2 = dist.topk(2, dim=-1).values
+    margin = (top2[:, 0] - top2[:, 1]).numpy()
+    ws = torch.empty(lib.wt_vq_workspace_bytes(N, bins), dtype=torch.uint8, device="cuda")
+    codes = torch.empty(N, dtype=torch.int64, device="cuda")
+    check(lib.wt_vq_nearest(_ptr(x.cuda()), _ptr(embed.cuda()), N, D, bins, _ptr(codes), _ptr(ws), None), "wt_vq_nearest")
+    torch.cuda.synchronize()
+    got = codes.cpu()
+    assert int(got[0]) == 17 and int(got[1]) == 2048 and int(got[2]) == 2048
+    # rows 0..2 have margin 0 by construction; everything else must match exactly
+    bad = (got != want).nonzero().flatten().tolist()
+    assert all(margin[i] < 1e-3 for i in bad), bad
+
+
+def test_seanet_decoder():
+    """Secondary path: feature_extractor.encodec.decoder(features) (seanet.py:147-238)."""
+    m, sd = _model("hop600", with_seanet_decoder=True)
+    orc = _oracle("hop600", sd)
+    gen = torch.Generator().manual_seed(5)
+    z = torch.randn(2, 512, 20, generator=gen) * 0.6
+    with torch.inference_mode():
+        want = orc.seanet_decoder(z)
+    got = m.feature_extractor.encodec.decoder(z.cuda())
+    assert tuple(got.shape) == tuple(want.shape) == (2, 1, 20 * 600)
+    assert rel_l2(got.cpu().numpy(), want.numpy()) < WAV_REL_TOL

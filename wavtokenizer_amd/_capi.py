@@ -1,0 +1,84 @@
+"""ctypes binding of libwavtok_hip.so (see include/wavtokenizer_amd.h).
+
+There is no CPU fallback: if the library is missing or fails to load, importing this
+module raises, and every caller of the product path fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwavtok_hip.so")
+
+# every symbol include/wavtokenizer_amd.h declares
+EXPORTS = [
+    "wt_last_error", "wt_version", "wt_model_create", "wt_model_destroy", "wt_model_hop", "wt_model_weight_bytes",
+    "wt_plan_create", "wt_plan_destroy", "wt_plan_workspace_bytes", "wt_plan_frames", "wt_plan_num_launches",
+    "wt_plan_find_buffer", "wt_plan_buffer_name", "wt_encode", "wt_codes_to_features", "wt_decode",
+    "wt_seanet_decode", "wt_sconv1d", "wt_vq_workspace_bytes", "wt_vq_nearest",
+]
+
+WT_PLAN_ENCODE, WT_PLAN_DECODE, WT_PLAN_SEANET_DECODER = 0, 1, 2
+WT_PLAN_FLAG_KEEP_STAGES = 1
+
+
+class WtArch(ctypes.Structure):
+    _fields_ = [("n_ratios", c_int32), ("ratios", c_int32 * 8), ("vq_bins", c_int32), ("num_quantizers", c_int32),
+                ("input_channels", c_int32), ("dim", c_int32), ("intermediate_dim", c_int32),
+                ("num_layers", c_int32), ("adanorm_num_embeddings", c_int32), ("n_fft", c_int32),
+                ("hop_length", c_int32), ("padding_same", c_int32)]
+
+
+class WtTensor(ctypes.Structure):
+    _fields_ = [("name", c_char_p), ("data", POINTER(c_float)), ("numel", c_int64)]
+
+
+class WavTokError(RuntimeError):
+    pass
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C wavtokenizer_amd/csrc). There is no CPU fallback for the product path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.wt_last_error.restype = c_char_p
+    lib.wt_version.restype = c_char_p
+    lib.wt_model_create.argtypes = [POINTER(WtArch), POINTER(WtTensor), c_int32, c_int32, POINTER(c_void_p)]
+    lib.wt_model_destroy.argtypes = [c_void_p]
+    lib.wt_model_destroy.restype = None
+    lib.wt_model_hop.argtypes = [c_void_p]
+    lib.wt_model_weight_bytes.argtypes = [c_void_p]
+    lib.wt_model_weight_bytes.restype = c_int64
+    lib.wt_plan_create.argtypes = [c_void_p, c_int32, c_int32, c_int64, c_int32, POINTER(c_void_p)]
+    lib.wt_plan_destroy.argtypes = [c_void_p]
+    lib.wt_plan_destroy.restype = None
+    lib.wt_plan_workspace_bytes.argtypes = [c_void_p]
+    lib.wt_plan_workspace_bytes.restype = c_size_t
+    lib.wt_plan_frames.argtypes = [c_void_p]
+    lib.wt_plan_frames.restype = c_int64
+    lib.wt_plan_num_launches.argtypes = [c_void_p]
+    lib.wt_plan_find_buffer.argtypes = [c_void_p, c_char_p, POINTER(c_size_t), POINTER(c_size_t)]
+    lib.wt_plan_buffer_name.argtypes = [c_void_p, c_int32, POINTER(c_char_p)]
+    lib.wt_encode.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.wt_codes_to_features.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p, c_void_p]
+    lib.wt_decode.argtypes = [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.wt_seanet_decode.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.wt_sconv1d.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32,
+                               c_int32, c_int32, c_int32, c_void_p]
+    lib.wt_vq_workspace_bytes.argtypes = [c_int64, c_int32]
+    lib.wt_vq_workspace_bytes.restype = c_size_t
+    lib.wt_vq_nearest.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib.wt_last_error()
+        raise WavTokError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")

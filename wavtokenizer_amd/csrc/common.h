@@ -1,0 +1,122 @@
+// Internal declarations shared by the HIP translation units of libwavtok_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+namespace wt {
+
+void set_error(const std::string& msg);
+
+#define WT_HIP_CHECK(expr)                                                                      \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            ::wt::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+            return -4;                                                                          \
+        }                                                                                       \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// The one dense-contraction kernel of the path: C = epilogue(prologue(gather(A)) . W^T)
+//   A  : activations, time-major rows [clip][time][channel]; a row of the im2col matrix for
+//        output frame t is the `taps` input rows (t*stride + tap*dil - pad_left), each `Cin` long,
+//        so K = taps*Cin and no im2col buffer exists.  Plain matrices are taps=1, stride=1.
+//   W  : [N][K] fp32, K contiguous (nn.Linear layout; conv weights repacked to [Cout][tap][Cin]).
+// Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32 multiply-add chain).
+// ---------------------------------------------------------------------------------------------
+enum Pro : int { PRO_NONE = 0, PRO_ELU = 1, PRO_AFFINE = 2, PRO_AFFINE_SWISH = 3 };
+enum Epi : int {
+    EPI_BIAS = 0,            // C = acc + bias[n]                        (bias may be null)
+    EPI_BIAS_RES = 1,        // C = (acc + bias[n]) + R[m][n]
+    EPI_BIAS_GELU = 2,       // C = gelu_erf(acc + bias[n])
+    EPI_BIAS_GAMMA_RES = 3,  // C = R[m][n] + gamma[n] * (acc + bias[n])
+    EPI_HEAD = 4,            // ISTFTHead: paired (log-mag, phase) column tiles -> re/im spectrum
+    EPI_OLA = 5,             // ISTFT overlap-add rows -> trimmed waveform / window envelope
+    EPI_ARGMAX = 6,          // VQ: per-row argmax of -(xx - 2 acc + ee[n]) over this wave's columns
+    EPI_SCALE = 7,           // C = alpha * acc
+    EPI_BIAS_ROW = 8         // C = acc + bias[m]
+};
+enum PadMode : int { PAD_ZERO = 0, PAD_REFLECT = 1 };
+
+struct GemmArgs {
+    // A gather
+    const float* A = nullptr;
+    long a_bstride = 0;   // elements between clips
+    long a_rstride = 0;   // elements between consecutive time rows of a clip
+    int T_in = 0, T_out = 0;     // rows per clip in / out;  M = nclips * T_out
+    int Cin = 0, taps = 1, stride = 1, dil = 1, pad_left = 0, pad_mode = PAD_ZERO;
+    int Tp = 0;           // reflect: effective length max(T_in, max_pad + 1) (conv.py:86-91)
+    const float* pro_scale = nullptr;  // [nclips][Cin]
+    const float* pro_shift = nullptr;
+    // W
+    const float* W = nullptr;
+    long w_rstride = 0;
+    const float* bias = nullptr;
+    int M = 0, N = 0, K = 0;
+    // C
+    float* C = nullptr;
+    long c_rstride = 0;
+    const float* R = nullptr;
+    long r_rstride = 0;
+    const float* gamma = nullptr;
+    float alpha = 1.f;
+    // batched over blockIdx.z
+    int nz = 1;
+    long zA = 0, zW = 0, zC = 0;
+    // EPI_HEAD
+    int head_kb = 0;      // padded bins per half; C row = [re (kb) | im (kb)]
+    // EPI_OLA
+    int ola_L = 0, ola_hop = 0, ola_pad = 0, ola_R = 0;
+    const float* ola_wsq = nullptr;   // window^2 [n_fft]
+    // EPI_ARGMAX
+    const float* vq_xx = nullptr;     // [M] row |x|^2
+    const float* vq_ee = nullptr;     // [N] |e|^2
+    float* vq_pval = nullptr;         // [M][vq_nparts]
+    int*   vq_pidx = nullptr;
+    int vq_nparts = 0;
+};
+
+enum TileCfg : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2, TILE_64x64 = 3 };
+int gemm_vq_parts(int N);   // partial (val, idx) slots per row written by EPI_ARGMAX
+int launch_gemm(const GemmArgs& a, int pro, int epi, hipStream_t s);
+int gemm_init();            // raises dynamic-LDS limits; call once per process/device
+
+// ------------------------------------------------------------------------ non-GEMM kernels
+int launch_conv_first(const float* wav, const float* w /*[7][Cout]*/, const float* bias, float* y, int B, long T,
+                      int k, int Cout, hipStream_t s);
+int launch_conv_last(const float* x /*[B][T][Cin]*/, const float* w /*[k][Cin]*/, const float* bias, float* y /*[B][T]*/,
+                     int B, long T, int Cin, int k, hipStream_t s);
+int launch_transpose(const float* in, float* out, int B, int R, int C, hipStream_t s);  // [B][R][C] -> [B][C][R]
+int launch_gn_stats(const float* x, const float* gamma, const float* beta, float* scale, float* shift, int B, int L,
+                    int C, int groups, float eps, hipStream_t s);
+int launch_affine(const float* x, const float* scale, const float* shift, float* y, int B, int L, int C, hipStream_t s);
+enum RowNormMode : int { RN_DWCONV = 0, RN_PLAIN = 1, RN_AFFINE_IN = 2 };
+int launch_rownorm(int mode, const float* x, float* y, int B, int L, int C, const float* dw_w /*[7][C]*/,
+                   const float* dw_b, const float* in_scale, const float* in_shift, const float* out_scale,
+                   const float* out_shift, float eps, hipStream_t s);
+int launch_softmax(float* S, int rows, int L, int ld, hipStream_t s);
+int launch_row_sumsq(const float* x, float* out, long rows, int D, hipStream_t s);
+int launch_vq_finalize(const float* pval, const int* pidx, int nparts, const float* embed, int64_t* codes,
+                       float* feat_ncl, int B, int L, int D, hipStream_t s);
+int launch_codes_to_features(const int64_t* codes, const float* embed, int K, int bins, int B, long L, int D,
+                             float* feat_ncl, hipStream_t s);
+struct LstmArgs {
+    const float* xg0;     // [B][L][4H] layer-0 input projection (+ both biases), packed gate order
+    const float* W0;      // [4H][H]   packed W_hh_l0
+    const float* W1;      // [4H][2H]  packed [W_ih_l1 | W_hh_l1]
+    const float* b1;      // [4H]      packed b_ih_l1 + b_hh_l1
+    float* h0;            // [2][B][H]
+    float* h1;            // [2][B][H]
+    float* c0;            // [B][H]
+    float* c1;            // [B][H]
+    const float* x;       // [B][L][H] skip input
+    float* y;             // [B][L][H] output = h1 + x
+    int B, L, H;
+};
+int launch_lstm_step(const LstmArgs& a, int s, hipStream_t stream);
+int launch_convtr(const float* x, const float* w /*[k][Cin][Cout]*/, const float* bias, float* y, int B, int Tin,
+                  int Cin, int Cout, int k, int stride, int elu_in, hipStream_t s);
+
+}  // namespace wt

@@ -1,0 +1,371 @@
+// fp32 MFMA implicit-GEMM for every dense contraction of the WavTokenizer path (gfx950).
+//
+//   C[m][n] = epi( sum_k pro(Agather[m][k]) * W[n][k] )
+//
+// * time-major activations make an im2col row a run of `taps` contiguous Cin-vectors, so a
+//   strided / dilated Conv1d (encoder/modules/conv.py:195-211, reflect padded) and a zero
+//   padded Conv1d (decoder/models.py:29-43,177) are this kernel with no im2col buffer;
+// * 128xBN block tile, 4 waves (64 lanes each), v_mfma_f32_32x32x2_f32: exact fp32 FMA chains
+//   at the fp32 matrix rate (157 TFLOP/s peak);
+// * both operands staged global -> registers -> LDS as [row][k] with a 36-float pitch:
+//   each lane fetches its four k-steps with one conflict-free ds_read_b128 (k order inside a
+//   step group is permuted identically for A and B, which a sum over k does not see);
+// * register-prefetched double buffering, one barrier per 32-deep K step;
+// * workgroup id -> tile remap keeps tiles that share A rows on one XCD's L2.
+#include "common.h"
+
+namespace wt {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr int BK = 32;
+static constexpr int LDS_PITCH = 36;   // floats; 144 B rows keep 16-B alignment, spread banks
+
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+    // bijective for any nwg (cdna guide T1): blocks orig, orig+8, ... share an XCD
+    int q = nwg >> 3, r = nwg & 7;
+    int xcd = orig & 7, idx = orig >> 3;
+    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+__device__ __forceinline__ float swish(float y) { return y / (1.f + expf(-y)); }
+__device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.f + erff(x * 0.70710678118654752440f)); }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PRO, int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int NA = BM / 32, NB = BN / 32;     // float4 staging loads per thread
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    static_assert(TM >= 1 && TN >= 1, "wave tile");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                               // [2][BM][PITCH]
+    float* Bs = smem + 2 * BM * LDS_PITCH;          // [2][BN][PITCH]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int bm = tile / tiles_n, bn = tile % tiles_n;
+    const int z = blockIdx.z;
+
+    const float* __restrict__ Ag = p.A + (long)z * p.zA;
+    const float* __restrict__ Wg = p.W + (long)z * p.zW;
+
+    // ---- per-thread staging rows (fixed across the K loop)
+    const int srow = tid >> 3;        // 0..31
+    const int kq4 = (tid & 7) * 4;    // k offset of this thread's float4 inside a K step
+    const float* a_base[NA];
+    int a_pos0[NA];
+    int a_clip[NA];
+    bool a_ok[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        int m = bm * BM + srow + 32 * i;
+        a_ok[i] = m < p.M;
+        int mm = a_ok[i] ? m : 0;
+        int b = mm / p.T_out;
+        int t = mm - b * p.T_out;
+        a_clip[i] = b;
+        a_base[i] = Ag + (long)b * p.a_bstride;
+        a_pos0[i] = t * p.stride - p.pad_left;
+    }
+    const float* w_base[NB];
+    bool w_ok[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        int n = bn * BN + srow + 32 * i;
+        w_ok[i] = n < p.N;
+        w_base[i] = Wg + (long)(w_ok[i] ? n : 0) * p.w_rstride;
+    }
+
+    f32x4 ra[NA], rb[NB];
+
+    auto load_tile = [&](int k0, int tap, int ci0) {
+        const int kk = k0 + kq4;
+        const bool kin = kk < p.K;
+        const int ci = ci0 + kq4;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            int pos = a_pos0[i] + tap * p.dil;
+            bool ok = a_ok[i] && kin;
+            if (p.pad_mode == PAD_REFLECT) {
+                if (pos < 0) pos = -pos;
+                if (pos >= p.Tp) pos = 2 * (p.Tp - 1) - pos;
+                ok = ok && (pos < p.T_in);
+            } else {
+                ok = ok && (pos >= 0) && (pos < p.T_in);
+            }
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                v = *reinterpret_cast<const f32x4*>(a_base[i] + (long)pos * p.a_rstride + ci);
+                if (PRO == PRO_ELU) {
+                    v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w);
+                } else if (PRO == PRO_AFFINE || PRO == PRO_AFFINE_SWISH) {
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.pro_scale + (long)a_clip[i] * p.Cin + ci);
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(p.pro_shift + (long)a_clip[i] * p.Cin + ci);
+                    v = v * sc + sh;
+                    if (PRO == PRO_AFFINE_SWISH) {
+                        v.x = swish(v.x); v.y = swish(v.y); v.z = swish(v.z); v.w = swish(v.w);
+                    }
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (w_ok[i] && kin) v = *reinterpret_cast<const f32x4*>(w_base[i] + kk);
+            rb[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* as = As + buf * BM * LDS_PITCH;
+        float* bs = Bs + buf * BN * LDS_PITCH;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            *reinterpret_cast<f32x4*>(as + (srow + 32 * i) * LDS_PITCH + kq4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            *reinterpret_cast<f32x4*>(bs + (srow + 32 * i) * LDS_PITCH + kq4) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (p.K + BK - 1) / BK;
+    // (tap, ci0) of the K step being loaded; host guarantees taps == 1 or Cin % 32 == 0
+    int tap = 0, ci0 = 0;
+    load_tile(0, tap, ci0);
+    store_tile(0);
+    __syncthreads();
+
+    const int frag_off = (lane & 31) * LDS_PITCH + 4 * (lane >> 5);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) {
+            ci0 += BK;
+            if (p.taps > 1 && ci0 >= p.Cin) { ci0 -= p.Cin; ++tap; }
+            load_tile((kt + 1) * BK, tap, ci0);
+        }
+        const float* as = As + buf * BM * LDS_PITCH + (wm * WM) * LDS_PITCH + frag_off;
+        const float* bs = Bs + buf * BN * LDS_PITCH + (wn * WN) * LDS_PITCH + frag_off;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDS_PITCH + q * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LDS_PITCH + q * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------------- epilogue
+    const int col_l = lane & 31;
+    const int row_h = 4 * (lane >> 5);
+    const int m_w = bm * BM + wm * WM;
+    const int n_w = bn * BN + wn * WN;
+
+    if constexpr (EPI == EPI_ARGMAX) {
+        // best over this wave's WN columns for each of its WM rows
+        const int part = bn * WAVES_N + wn;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_w + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+                const float xx = (m < p.M) ? p.vq_xx[m] : 0.f;
+                float best = -INFINITY;
+                int bidx = 0x7fffffff;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n_w + j * 32 + col_l;
+                    if (n < p.N) {
+                        // core_vq.py:177-181: -(|x|^2 - 2 x.e + |e|^2), same association
+                        const float d = -((xx - 2.f * acc[i][j][r]) + p.vq_ee[n]);
+                        if (d > best || (d == best && n < bidx)) { best = d; bidx = n; }
+                    }
+                }
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) {
+                    const float ov = __shfl_xor(best, off, 64);
+                    const int oi = __shfl_xor(bidx, off, 64);
+                    if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+                }
+                if (col_l == 0 && m < p.M) {
+                    p.vq_pval[(long)m * p.vq_nparts + part] = best;
+                    p.vq_pidx[(long)m * p.vq_nparts + part] = bidx;
+                }
+            }
+        }
+        return;
+    }
+
+    float* __restrict__ Cg = p.C + (long)z * p.zC;
+    if constexpr (EPI == EPI_HEAD) {
+        static_assert(TN % 2 == 0, "head epilogue pairs column tiles");
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j + 1 < TN; j += 2) {
+                const int pc = n_w + j * 32 + col_l;        // packed column of the log-magnitude
+                if (pc < p.N) {   // N % 64 == 0, so the paired phase column pc+32 is in range too
+                    const float bmag = p.bias[pc], bph = p.bias[pc + 32];
+                    const int f = (pc >> 6) * 32 + col_l;   // frequency bin
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m_w + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+                        if (m < p.M) {
+                            float mag = expf(acc[i][j][r] + bmag);          // heads.py:55
+                            mag = fminf(mag, 100.f);                         // heads.py:56 clip(max=1e2)
+                            const float ph = acc[i][j + 1][r] + bph;
+                            Cg[(long)m * p.c_rstride + f] = mag * cosf(ph);  // heads.py:58,65
+                            Cg[(long)m * p.c_rstride + p.head_kb + f] = mag * sinf(ph);
+                        }
+                    }
+                }
+            }
+        return;
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n_w + j * 32 + col_l;
+            if (n >= p.N) continue;
+            float bn_ = 0.f, gm = 1.f;
+            if (EPI == EPI_BIAS || EPI == EPI_BIAS_RES || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GAMMA_RES)
+                bn_ = p.bias ? p.bias[n] : 0.f;
+            if (EPI == EPI_BIAS_GAMMA_RES) gm = p.gamma[n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_w + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r];
+                if (EPI == EPI_BIAS) {
+                    Cg[(long)m * p.c_rstride + n] = v + bn_;
+                } else if (EPI == EPI_BIAS_RES) {
+                    Cg[(long)m * p.c_rstride + n] = (v + bn_) + p.R[(long)m * p.r_rstride + n];
+                } else if (EPI == EPI_BIAS_GELU) {
+                    Cg[(long)m * p.c_rstride + n] = gelu_erf(v + bn_);
+                } else if (EPI == EPI_BIAS_GAMMA_RES) {
+                    Cg[(long)m * p.c_rstride + n] = p.R[(long)m * p.r_rstride + n] + gm * (v + bn_);
+                } else if (EPI == EPI_SCALE) {
+                    Cg[(long)m * p.c_rstride + n] = v * p.alpha;
+                } else if (EPI == EPI_BIAS_ROW) {
+                    Cg[(long)m * p.c_rstride + n] = v + p.bias[m];
+                } else if (EPI == EPI_OLA) {
+                    // spectral_ops.py:60-73: frame rows already windowed by the basis; row m is
+                    // hop-aligned block j' of the un-trimmed signal, column n its sample r
+                    const int b = m / p.T_out;
+                    const int jp = m - b * p.T_out;
+                    const long u = (long)p.ola_hop * jp + n - p.ola_pad;
+                    if (u >= 0 && u < (long)p.ola_hop * p.ola_L) {
+                        float env = 0.f;
+                        for (int d = 0; d < p.ola_R; ++d) {
+                            const int tt = jp - d;
+                            if (tt >= 0 && tt < p.ola_L) env += p.ola_wsq[n + p.ola_hop * d];
+                        }
+                        Cg[(long)b * p.ola_hop * p.ola_L + u] = v / env;
+                    }
+                }
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------- host side
+template <int BM, int BN, int WMs, int WNs, int PRO, int EPI>
+static int launch_one(const GemmArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    constexpr size_t smem = 2ull * (BM + BN) * LDS_PITCH * sizeof(float);
+    auto kern = gemm_kernel<BM, BN, WMs, WNs, PRO, EPI>;
+    if (!attr_set) {
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+    dim3 grid(tiles_m * tiles_n, 1, a.nz);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
+    WT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <int PRO, int EPI>
+static int launch_tiled(const GemmArgs& a, hipStream_t s) {
+    if constexpr (EPI == EPI_HEAD || EPI == EPI_ARGMAX) {
+        return launch_one<128, 128, 2, 2, PRO, EPI>(a, s);
+    } else {
+        if (a.N <= 32) return launch_one<128, 32, 4, 1, PRO, EPI>(a, s);
+        if (a.N <= 64) return launch_one<128, 64, 2, 2, PRO, EPI>(a, s);
+        return launch_one<128, 128, 2, 2, PRO, EPI>(a, s);
+    }
+}
+
+int gemm_vq_parts(int N) { return ((N + 127) / 128) * 2; }
+
+int gemm_init() { return 0; }
+
+static int check_args(const GemmArgs& a) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0) { set_error("gemm: empty problem"); return -1; }
+    if (a.K % 4 != 0 || a.Cin % 4 != 0) { set_error("gemm: K and Cin must be multiples of 4"); return -1; }
+    if (a.taps > 1 && a.Cin % BK != 0) { set_error("gemm: multi-tap gather needs Cin % 32 == 0"); return -1; }
+    if (a.K != a.taps * a.Cin) { set_error("gemm: K != taps*Cin"); return -1; }
+    if (a.T_out <= 0 || a.M % a.T_out != 0) { set_error("gemm: M must be nclips*T_out"); return -1; }
+    if ((a.a_rstride % 4) || (a.a_bstride % 4) || (a.w_rstride % 4) || (a.zA % 4) || (a.zW % 4)) {
+        set_error("gemm: operand strides must keep 16-byte alignment"); return -1;
+    }
+    if ((reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.W) & 15)) {
+        set_error("gemm: operand base pointers must be 16-byte aligned"); return -1;
+    }
+    if (a.pad_mode == PAD_REFLECT && a.Tp < a.T_in) { set_error("gemm: reflect Tp < T_in"); return -1; }
+    return 0;
+}
+
+int launch_gemm(const GemmArgs& a, int pro, int epi, hipStream_t s) {
+    if (int rc = check_args(a)) return rc;
+#define WT_CASE(P, E) \
+    if (pro == P && epi == E) return launch_tiled<P, E>(a, s);
+    // the (prologue, epilogue) pairs the plans use
+    WT_CASE(PRO_NONE, EPI_BIAS)
+    WT_CASE(PRO_ELU, EPI_BIAS)
+    WT_CASE(PRO_ELU, EPI_BIAS_RES)
+    WT_CASE(PRO_NONE, EPI_BIAS_RES)
+    WT_CASE(PRO_AFFINE_SWISH, EPI_BIAS)
+    WT_CASE(PRO_AFFINE_SWISH, EPI_BIAS_RES)
+    WT_CASE(PRO_AFFINE, EPI_BIAS)
+    WT_CASE(PRO_NONE, EPI_BIAS_GELU)
+    WT_CASE(PRO_NONE, EPI_BIAS_GAMMA_RES)
+    WT_CASE(PRO_NONE, EPI_HEAD)
+    WT_CASE(PRO_NONE, EPI_OLA)
+    WT_CASE(PRO_NONE, EPI_ARGMAX)
+    WT_CASE(PRO_NONE, EPI_SCALE)
+    WT_CASE(PRO_NONE, EPI_BIAS_ROW)
+#undef WT_CASE
+    set_error("gemm: unsupported prologue/epilogue pair");
+    return -1;
+}
+
+}  // namespace wt

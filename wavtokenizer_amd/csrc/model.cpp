@@ -1,0 +1,1024 @@
+// Host side of libwavtok_hip.so: weight folding/packing (once, at wt_model_create), launch plans
+// (per (kind, B, len)) and the extern "C" entry points declared in include/wavtokenizer_amd.h.
+// No compute happens on the host at call time; a plan is a flat list of kernel launches over a
+// caller-owned workspace.
+#include "../../include/wavtokenizer_amd.h"
+#include "common.h"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace wt {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+// ------------------------------------------------------------------------------------- model
+struct ConvW {
+    float* w = nullptr;   // [cout][k][cin]
+    float* b = nullptr;   // [cout]
+    int cout = 0, cin = 0, k = 0;
+};
+struct LstmW {
+    float* Wih0 = nullptr;  // [4H][H] rows in packed gate order
+    float* b0 = nullptr;    // [4H]  b_ih_l0 + b_hh_l0, packed
+    float* W0 = nullptr;    // [4H][H]  W_hh_l0 packed
+    float* W1 = nullptr;    // [4H][2H] [W_ih_l1 | W_hh_l1] packed
+    float* b1 = nullptr;    // [4H]
+};
+struct ResStage {
+    ConvW c3, c1, sc, down;
+    int C = 0, r = 0;
+};
+struct PosRes {
+    float *n1w, *n1b, *n2w, *n2b;
+    ConvW c1, c2;
+};
+struct CnxBlock {
+    float *dw_w, *dw_b, *ada_s, *ada_h, *W1, *b1, *W2, *b2, *gamma;
+};
+struct SeaDecStage {
+    float* tr_w = nullptr;  // [k][cin][cout]
+    float* tr_b = nullptr;
+    int cin = 0, cout = 0, k = 0, r = 0;
+    ConvW c3, c1, sc;
+};
+
+}  // namespace wt
+
+struct wt_model {
+    wt_arch arch{};
+    int device = 0;
+    int hop = 1;
+    int H = 512;
+    std::vector<int> enc_ratios;
+    std::vector<void*> allocs;
+    int64_t weight_bytes = 0;
+    // encoder
+    float *e0_w = nullptr, *e0_b = nullptr;   // [7][32], [32]
+    int e0_k = 7, e0_c = 32;
+    std::vector<wt::ResStage> stages;
+    wt::LstmW enc_lstm;
+    wt::ConvW enc_final;
+    float *embed = nullptr, *ee = nullptr;
+    // backbone
+    wt::ConvW bb_embed;
+    wt::PosRes res[4];
+    float *at_nw, *at_nb, *at_Wqk, *at_bqk, *at_Wv, *at_bv, *at_Wp, *at_bp;
+    float *gn5w, *gn5b, *ada_s, *ada_h;
+    std::vector<wt::CnxBlock> cnx;
+    float *fln_w, *fln_b;
+    float *head_W = nullptr, *head_b = nullptr;
+    int Kb = 0, bins_f = 0, R = 0;
+    float *istft_W = nullptr, *wsq = nullptr;
+    // SEANetDecoder (present iff the checkpoint holds it)
+    bool has_seadec = false;
+    wt::ConvW sd_first;
+    wt::LstmW sd_lstm;
+    std::vector<wt::SeaDecStage> sd_stages;
+    float *sd_last_w = nullptr, *sd_last_b = nullptr;   // [7][32], [1]
+};
+
+namespace wt {
+
+struct TensorMap {
+    std::map<std::string, std::pair<const float*, int64_t>> m;
+    std::string missing;
+    const float* get(const std::string& k, int64_t numel) {
+        auto it = m.find(k);
+        if (it == m.end()) { if (missing.empty()) missing = k; return nullptr; }
+        if (it->second.second != numel) {
+            if (missing.empty()) missing = k + " (numel " + std::to_string(it->second.second) + ", expected " + std::to_string(numel) + ")";
+            return nullptr;
+        }
+        return it->second.first;
+    }
+    bool has(const std::string& k) const { return m.count(k) != 0; }
+};
+
+static int upload(wt_model* M, const std::vector<float>& h, float** out) {
+    void* d = nullptr;
+    size_t bytes = std::max<size_t>(h.size(), 4) * sizeof(float);
+    WT_HIP_CHECK(hipMalloc(&d, bytes));
+    M->allocs.push_back(d);
+    WT_HIP_CHECK(hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    M->weight_bytes += (int64_t)h.size() * sizeof(float);
+    *out = static_cast<float*>(d);
+    return 0;
+}
+static int upload_raw(wt_model* M, const float* src, int64_t n, float** out) {
+    std::vector<float> h(src, src + n);
+    return upload(M, h, out);
+}
+
+// weight_norm fold (torch.nn.utils.weight_norm, dim=0; conv.py:25-34): w[o] = g[o] * v[o] / ||v[o]||
+static std::vector<float> fold_wn(const float* g, const float* v, int d0, int64_t inner) {
+    std::vector<float> w((size_t)d0 * inner);
+    for (int o = 0; o < d0; ++o) {
+        double ss = 0.0;
+        for (int64_t i = 0; i < inner; ++i) { double x = v[o * inner + i]; ss += x * x; }
+        const double sc = (double)g[o] / std::sqrt(ss);
+        for (int64_t i = 0; i < inner; ++i) w[o * inner + i] = (float)(sc * (double)v[o * inner + i]);
+    }
+    return w;
+}
+
+// [cout][cin][k] -> [cout][k][cin]
+static std::vector<float> repack_ock(const std::vector<float>& w, int cout, int cin, int k) {
+    std::vector<float> o(w.size());
+    for (int a = 0; a < cout; ++a)
+        for (int c = 0; c < cin; ++c)
+            for (int j = 0; j < k; ++j) o[((size_t)a * k + j) * cin + c] = w[((size_t)a * cin + c) * k + j];
+    return o;
+}
+
+static int load_wn_conv(wt_model* M, TensorMap& tm, const std::string& prefix, int cout, int cin, int k, ConvW* out) {
+    const float* g = tm.get(prefix + ".weight_g", cout);
+    const float* v = tm.get(prefix + ".weight_v", (int64_t)cout * cin * k);
+    const float* b = tm.get(prefix + ".bias", cout);
+    if (!g || !v || !b) return WT_ERR_MISSING_TENSOR;
+    std::vector<float> w = repack_ock(fold_wn(g, v, cout, (int64_t)cin * k), cout, cin, k);
+    out->cout = cout; out->cin = cin; out->k = k;
+    if (int rc = upload(M, w, &out->w)) return rc;
+    return upload_raw(M, b, cout, &out->b);
+}
+
+static int load_plain_conv(wt_model* M, TensorMap& tm, const std::string& prefix, int cout, int cin, int k, ConvW* out) {
+    const float* w = tm.get(prefix + ".weight", (int64_t)cout * cin * k);
+    const float* b = tm.get(prefix + ".bias", cout);
+    if (!w || !b) return WT_ERR_MISSING_TENSOR;
+    std::vector<float> wv(w, w + (int64_t)cout * cin * k);
+    std::vector<float> p = repack_ock(wv, cout, cin, k);
+    out->cout = cout; out->cin = cin; out->k = k;
+    if (int rc = upload(M, p, &out->w)) return rc;
+    return upload_raw(M, b, cout, &out->b);
+}
+
+static int load_vec(wt_model* M, TensorMap& tm, const std::string& key, int64_t n, float** out) {
+    const float* p = tm.get(key, n);
+    if (!p) return WT_ERR_MISSING_TENSOR;
+    return upload_raw(M, p, n, out);
+}
+
+// nn.LSTM weights -> packed gate order: packed row (j/4)*16 + g*4 + j%4  <-  row g*H + j
+static int load_lstm(wt_model* M, TensorMap& tm, const std::string& prefix, int H, LstmW* out) {
+    const float* wih0 = tm.get(prefix + ".lstm.weight_ih_l0", 4LL * H * H);
+    const float* whh0 = tm.get(prefix + ".lstm.weight_hh_l0", 4LL * H * H);
+    const float* bih0 = tm.get(prefix + ".lstm.bias_ih_l0", 4LL * H);
+    const float* bhh0 = tm.get(prefix + ".lstm.bias_hh_l0", 4LL * H);
+    const float* wih1 = tm.get(prefix + ".lstm.weight_ih_l1", 4LL * H * H);
+    const float* whh1 = tm.get(prefix + ".lstm.weight_hh_l1", 4LL * H * H);
+    const float* bih1 = tm.get(prefix + ".lstm.bias_ih_l1", 4LL * H);
+    const float* bhh1 = tm.get(prefix + ".lstm.bias_hh_l1", 4LL * H);
+    if (!wih0 || !whh0 || !bih0 || !bhh0 || !wih1 || !whh1 || !bih1 || !bhh1) return WT_ERR_MISSING_TENSOR;
+    std::vector<float> Wih0((size_t)4 * H * H), W0((size_t)4 * H * H), W1((size_t)4 * H * 2 * H), b0(4 * H), b1(4 * H);
+    for (int g = 0; g < 4; ++g)
+        for (int j = 0; j < H; ++j) {
+            const size_t src = (size_t)g * H + j;
+            const size_t dst = (size_t)(j / 4) * 16 + g * 4 + (j % 4);
+            std::memcpy(&Wih0[dst * H], &wih0[src * H], H * sizeof(float));
+            std::memcpy(&W0[dst * H], &whh0[src * H], H * sizeof(float));
+            std::memcpy(&W1[dst * 2 * H], &wih1[src * H], H * sizeof(float));
+            std::memcpy(&W1[dst * 2 * H + H], &whh1[src * H], H * sizeof(float));
+            b0[dst] = bih0[src] + bhh0[src];
+            b1[dst] = bih1[src] + bhh1[src];
+        }
+    if (int rc = upload(M, Wih0, &out->Wih0)) return rc;
+    if (int rc = upload(M, b0, &out->b0)) return rc;
+    if (int rc = upload(M, W0, &out->W0)) return rc;
+    if (int rc = upload(M, W1, &out->W1)) return rc;
+    return upload(M, b1, &out->b1);
+}
+
+static const char* ENC = "feature_extractor.encodec.encoder.model.";
+static const char* DEC = "feature_extractor.encodec.decoder.model.";
+static const char* VQK = "feature_extractor.encodec.quantizer.vq.layers.0._codebook.";
+
+static int build_model(wt_model* M, TensorMap& tm) {
+    const wt_arch& a = M->arch;
+    const int nf = 32, H = 512;
+    M->H = H;
+    // ---- encoder (encoder/modules/seanet.py:66-144)
+    {
+        const float* g = tm.get(std::string(ENC) + "0.conv.conv.weight_g", nf);
+        const float* v = tm.get(std::string(ENC) + "0.conv.conv.weight_v", (int64_t)nf * 7);
+        const float* b = tm.get(std::string(ENC) + "0.conv.conv.bias", nf);
+        if (!g || !v || !b) return WT_ERR_MISSING_TENSOR;
+        std::vector<float> w = fold_wn(g, v, nf, 7);       // [32][1][7]
+        std::vector<float> p((size_t)7 * nf);
+        for (int c = 0; c < nf; ++c)
+            for (int j = 0; j < 7; ++j) p[(size_t)j * nf + c] = w[(size_t)c * 7 + j];
+        if (int rc = upload(M, p, &M->e0_w)) return rc;
+        if (int rc = upload_raw(M, b, nf, &M->e0_b)) return rc;
+    }
+    int idx = 1, mult = 1;
+    for (int r : M->enc_ratios) {
+        ResStage st;
+        st.C = mult * nf; st.r = r;
+        const std::string p = std::string(ENC) + std::to_string(idx);
+        if (int rc = load_wn_conv(M, tm, p + ".block.1.conv.conv", st.C / 2, st.C, 3, &st.c3)) return rc;
+        if (int rc = load_wn_conv(M, tm, p + ".block.3.conv.conv", st.C, st.C / 2, 1, &st.c1)) return rc;
+        if (int rc = load_wn_conv(M, tm, p + ".shortcut.conv.conv", st.C, st.C, 1, &st.sc)) return rc;
+        if (int rc = load_wn_conv(M, tm, std::string(ENC) + std::to_string(idx + 2) + ".conv.conv", 2 * st.C, st.C, 2 * r, &st.down)) return rc;
+        M->stages.push_back(st);
+        idx += 3; mult *= 2;
+    }
+    if (mult * nf != H) { set_error("encoder width after the last ratio must be 512"); return WT_ERR_INVALID; }
+    if (int rc = load_lstm(M, tm, std::string(ENC) + std::to_string(idx), H, &M->enc_lstm)) return rc;
+    if (int rc = load_wn_conv(M, tm, std::string(ENC) + std::to_string(idx + 2) + ".conv.conv", 512, H, 7, &M->enc_final)) return rc;
+
+    // ---- codebook (encoder/quantization/core_vq.py:122-138)
+    {
+        const float* inited = tm.get(std::string(VQK) + "inited", 1);
+        const float* e = tm.get(std::string(VQK) + "embed", (int64_t)a.vq_bins * 512);
+        if (!inited || !e) return WT_ERR_MISSING_TENSOR;
+        if (inited[0] != 1.0f) {
+            set_error("codebook buffer `inited` is not 1: the reference would run k-means on the first forward (core_vq.py:140-151)");
+            return WT_ERR_NOT_INITED;
+        }
+        if (int rc = upload_raw(M, e, (int64_t)a.vq_bins * 512, &M->embed)) return rc;
+        std::vector<float> ee(a.vq_bins);
+        for (int n = 0; n < a.vq_bins; ++n) {   // embed.pow(2).sum(0)
+            float s = 0.f;
+            for (int c = 0; c < 512; ++c) s += e[(size_t)n * 512 + c] * e[(size_t)n * 512 + c];
+            ee[n] = s;
+        }
+        if (int rc = upload(M, ee, &M->ee)) return rc;
+    }
+
+    // ---- backbone (decoder/models.py:166-216)
+    const int D = a.dim, I = a.intermediate_dim, A = a.adanorm_num_embeddings;
+    if (int rc = load_plain_conv(M, tm, "backbone.embed", D, a.input_channels, 7, &M->bb_embed)) return rc;
+    const int ridx[4] = {0, 1, 3, 4};
+    for (int i = 0; i < 4; ++i) {
+        const std::string p = "backbone.pos_net." + std::to_string(ridx[i]);
+        PosRes& r = M->res[i];
+        if (int rc = load_vec(M, tm, p + ".norm1.weight", D, &r.n1w)) return rc;
+        if (int rc = load_vec(M, tm, p + ".norm1.bias", D, &r.n1b)) return rc;
+        if (int rc = load_vec(M, tm, p + ".norm2.weight", D, &r.n2w)) return rc;
+        if (int rc = load_vec(M, tm, p + ".norm2.bias", D, &r.n2b)) return rc;
+        if (int rc = load_plain_conv(M, tm, p + ".conv1", D, D, 3, &r.c1)) return rc;
+        if (int rc = load_plain_conv(M, tm, p + ".conv2", D, D, 3, &r.c2)) return rc;
+    }
+    {
+        const std::string p = "backbone.pos_net.2";
+        if (int rc = load_vec(M, tm, p + ".norm.weight", D, &M->at_nw)) return rc;
+        if (int rc = load_vec(M, tm, p + ".norm.bias", D, &M->at_nb)) return rc;
+        const float* wq = tm.get(p + ".q.weight", (int64_t)D * D);
+        const float* wk = tm.get(p + ".k.weight", (int64_t)D * D);
+        const float* bq = tm.get(p + ".q.bias", D);
+        const float* bk = tm.get(p + ".k.bias", D);
+        if (!wq || !wk || !bq || !bk) return WT_ERR_MISSING_TENSOR;
+        std::vector<float> wqk((size_t)2 * D * D), bqk(2 * D);
+        std::memcpy(&wqk[0], wq, (size_t)D * D * sizeof(float));
+        std::memcpy(&wqk[(size_t)D * D], wk, (size_t)D * D * sizeof(float));
+        std::memcpy(&bqk[0], bq, D * sizeof(float));
+        std::memcpy(&bqk[D], bk, D * sizeof(float));
+        if (int rc = upload(M, wqk, &M->at_Wqk)) return rc;
+        if (int rc = upload(M, bqk, &M->at_bqk)) return rc;
+        if (int rc = load_vec(M, tm, p + ".v.weight", (int64_t)D * D, &M->at_Wv)) return rc;
+        if (int rc = load_vec(M, tm, p + ".v.bias", D, &M->at_bv)) return rc;
+        if (int rc = load_vec(M, tm, p + ".proj_out.weight", (int64_t)D * D, &M->at_Wp)) return rc;
+        if (int rc = load_vec(M, tm, p + ".proj_out.bias", D, &M->at_bp)) return rc;
+    }
+    if (int rc = load_vec(M, tm, "backbone.pos_net.5.weight", D, &M->gn5w)) return rc;
+    if (int rc = load_vec(M, tm, "backbone.pos_net.5.bias", D, &M->gn5b)) return rc;
+    if (A <= 0) { set_error("only the AdaLayerNorm (adanorm_num_embeddings > 0) backbone is implemented"); return WT_ERR_INVALID; }
+    if (int rc = load_vec(M, tm, "backbone.norm.scale.weight", (int64_t)A * D, &M->ada_s)) return rc;
+    if (int rc = load_vec(M, tm, "backbone.norm.shift.weight", (int64_t)A * D, &M->ada_h)) return rc;
+    for (int i = 0; i < a.num_layers; ++i) {
+        const std::string p = "backbone.convnext." + std::to_string(i);
+        CnxBlock c;
+        const float* dw = tm.get(p + ".dwconv.weight", (int64_t)D * 7);
+        if (!dw) return WT_ERR_MISSING_TENSOR;
+        std::vector<float> dwp((size_t)7 * D);
+        for (int ch = 0; ch < D; ++ch)
+            for (int j = 0; j < 7; ++j) dwp[(size_t)j * D + ch] = dw[(size_t)ch * 7 + j];
+        if (int rc = upload(M, dwp, &c.dw_w)) return rc;
+        if (int rc = load_vec(M, tm, p + ".dwconv.bias", D, &c.dw_b)) return rc;
+        if (int rc = load_vec(M, tm, p + ".norm.scale.weight", (int64_t)A * D, &c.ada_s)) return rc;
+        if (int rc = load_vec(M, tm, p + ".norm.shift.weight", (int64_t)A * D, &c.ada_h)) return rc;
+        if (int rc = load_vec(M, tm, p + ".pwconv1.weight", (int64_t)I * D, &c.W1)) return rc;
+        if (int rc = load_vec(M, tm, p + ".pwconv1.bias", I, &c.b1)) return rc;
+        if (int rc = load_vec(M, tm, p + ".pwconv2.weight", (int64_t)D * I, &c.W2)) return rc;
+        if (int rc = load_vec(M, tm, p + ".pwconv2.bias", D, &c.b2)) return rc;
+        if (int rc = load_vec(M, tm, p + ".gamma", D, &c.gamma)) return rc;
+        M->cnx.push_back(c);
+    }
+    if (int rc = load_vec(M, tm, "backbone.final_layer_norm.weight", D, &M->fln_w)) return rc;
+    if (int rc = load_vec(M, tm, "backbone.final_layer_norm.bias", D, &M->fln_b)) return rc;
+
+    // ---- head (decoder/heads.py:36-67, decoder/spectral_ops.py:33-75)
+    {
+        const int N = a.n_fft, hop = a.hop_length;
+        if (N % hop != 0 || N % 2 != 0 || (N - hop) % 2 != 0) {
+            set_error("ISTFT kernel needs n_fft to be an even multiple of hop_length"); return WT_ERR_INVALID;
+        }
+        const int bins = N / 2 + 1;
+        const int Kb = ((bins + 31) / 32) * 32;
+        const int R = N / hop;
+        M->Kb = Kb; M->bins_f = bins; M->R = R;
+        const float* w = tm.get("head.out.weight", (int64_t)(N + 2) * D);
+        const float* b = tm.get("head.out.bias", N + 2);
+        const float* win = tm.get("head.istft.window", N);
+        if (!w || !b || !win) return WT_ERR_MISSING_TENSOR;
+        // packed rows: 64-row groups = 32 log-magnitude rows then the 32 phase rows of the same bins
+        std::vector<float> wp((size_t)2 * Kb * D, 0.f), bp((size_t)2 * Kb, 0.f);
+        for (int f = 0; f < bins; ++f) {
+            const size_t pm = (size_t)(f / 32) * 64 + (f % 32), pp = pm + 32;
+            std::memcpy(&wp[pm * D], &w[(size_t)f * D], D * sizeof(float));
+            std::memcpy(&wp[pp * D], &w[(size_t)(bins + f) * D], D * sizeof(float));
+            bp[pm] = b[f];
+            bp[pp] = b[bins + f];
+        }
+        if (int rc = upload(M, wp, &M->head_W)) return rc;
+        if (int rc = upload(M, bp, &M->head_b)) return rc;
+        // windowed inverse real-DFT basis, one K block per overlapping frame (see gemm.hip EPI_OLA)
+        const size_t Kt = (size_t)R * 2 * Kb;
+        std::vector<float> basis((size_t)hop * Kt, 0.f);
+        const double two_pi = 6.283185307179586476925286766559;
+        for (int r = 0; r < hop; ++r)
+            for (int tau = 0; tau < R; ++tau) {
+                const int d = R - 1 - tau;
+                const int n = r + hop * d;
+                const double wn = (double)win[n] / (double)N;
+                float* row = &basis[(size_t)r * Kt + (size_t)tau * 2 * Kb];
+                for (int f = 0; f < bins; ++f) {
+                    const bool edge = (f == 0) || (f == N / 2);
+                    const double cf = edge ? 1.0 : 2.0;
+                    const long ph = ((long)f * n) % N;
+                    const double th = two_pi * (double)ph / (double)N;
+                    row[f] = (float)(cf * std::cos(th) * wn);
+                    row[Kb + f] = edge ? 0.f : (float)(-cf * std::sin(th) * wn);   // C2R ignores Im of DC/Nyquist
+                }
+            }
+        if (int rc = upload(M, basis, &M->istft_W)) return rc;
+        std::vector<float> wsq(N);
+        for (int n = 0; n < N; ++n) wsq[n] = win[n] * win[n];
+        if (int rc = upload(M, wsq, &M->wsq)) return rc;
+    }
+
+    // ---- optional SEANetDecoder (encoder/modules/seanet.py:147-238)
+    M->has_seadec = tm.has(std::string(DEC) + "0.conv.conv.weight_v");
+    if (M->has_seadec) {
+        int m2 = 1 << a.n_ratios;
+        if (int rc = load_wn_conv(M, tm, std::string(DEC) + "0.conv.conv", m2 * nf, 512, 7, &M->sd_first)) return rc;
+        if (int rc = load_lstm(M, tm, std::string(DEC) + "1", H, &M->sd_lstm)) return rc;
+        int di = 2;
+        for (int i = 0; i < a.n_ratios; ++i) {
+            const int r = a.ratios[i];
+            SeaDecStage st;
+            st.cin = m2 * nf; st.cout = st.cin / 2; st.k = 2 * r; st.r = r;
+            const std::string p = std::string(DEC) + std::to_string(di + 1) + ".convtr.convtr";
+            const float* g = tm.get(p + ".weight_g", st.cin);
+            const float* v = tm.get(p + ".weight_v", (int64_t)st.cin * st.cout * st.k);
+            const float* b = tm.get(p + ".bias", st.cout);
+            if (!g || !v || !b) return WT_ERR_MISSING_TENSOR;
+            std::vector<float> w = fold_wn(g, v, st.cin, (int64_t)st.cout * st.k);   // [cin][cout][k], g per cin
+            std::vector<float> pk((size_t)st.k * st.cin * st.cout);
+            for (int ci = 0; ci < st.cin; ++ci)
+                for (int co = 0; co < st.cout; ++co)
+                    for (int j = 0; j < st.k; ++j)
+                        pk[((size_t)j * st.cin + ci) * st.cout + co] = w[((size_t)ci * st.cout + co) * st.k + j];
+            if (int rc = upload(M, pk, &st.tr_w)) return rc;
+            if (int rc = upload_raw(M, b, st.cout, &st.tr_b)) return rc;
+            const std::string rp = std::string(DEC) + std::to_string(di + 2);
+            const int h = st.cout;
+            if (int rc = load_wn_conv(M, tm, rp + ".block.1.conv.conv", h / 2, h, 3, &st.c3)) return rc;
+            if (int rc = load_wn_conv(M, tm, rp + ".block.3.conv.conv", h, h / 2, 1, &st.c1)) return rc;
+            if (int rc = load_wn_conv(M, tm, rp + ".shortcut.conv.conv", h, h, 1, &st.sc)) return rc;
+            M->sd_stages.push_back(st);
+            di += 3; m2 /= 2;
+        }
+        const std::string p = std::string(DEC) + std::to_string(di + 1) + ".conv.conv";
+        const float* g = tm.get(p + ".weight_g", 1);
+        const float* v = tm.get(p + ".weight_v", (int64_t)nf * 7);
+        const float* b = tm.get(p + ".bias", 1);
+        if (!g || !v || !b) return WT_ERR_MISSING_TENSOR;
+        std::vector<float> w = fold_wn(g, v, 1, (int64_t)nf * 7);   // [1][32][7]
+        std::vector<float> pk((size_t)7 * nf);
+        for (int c = 0; c < nf; ++c)
+            for (int j = 0; j < 7; ++j) pk[(size_t)j * nf + c] = w[(size_t)c * 7 + j];
+        if (int rc = upload(M, pk, &M->sd_last_w)) return rc;
+        if (int rc = upload_raw(M, b, 1, &M->sd_last_b)) return rc;
+    }
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------- plan
+struct RunCtx {
+    char* ws;
+    hipStream_t stream;
+    const float* in_f;       // wav (encode) / features (decode)
+    float* out_f;            // features (encode) / wav (decode)
+    int64_t* codes;
+    float* aux;              // emb_out (encode) / backbone_out (decode)
+    int bw_id;
+};
+struct BufSpec {
+    std::string name;
+    size_t bytes = 0, numel = 0, off = 0;
+    int first = INT_MAX, last = -1;
+};
+
+}  // namespace wt
+
+struct wt_plan {
+    const wt_model* model = nullptr;
+    int kind = 0, B = 0, flags = 0;
+    int64_t len = 0, L = 0, T = 0;
+    std::vector<wt::BufSpec> bufs;
+    std::vector<std::function<int(const wt::RunCtx&)>> steps;
+    size_t ws_bytes = 0;
+    int n_launches = 0;
+
+    int buf(const std::string& name, size_t numel) {
+        wt::BufSpec b;
+        b.name = name; b.numel = numel; b.bytes = (numel * sizeof(float) + 255) / 256 * 256;
+        bufs.push_back(b);
+        return (int)bufs.size() - 1;
+    }
+    void step(std::initializer_list<int> used, std::function<int(const wt::RunCtx&)> fn, int launches = 1) {
+        const int s = (int)steps.size();
+        for (int id : used) {
+            if (id < 0) continue;
+            bufs[id].first = std::min(bufs[id].first, s);
+            bufs[id].last = std::max(bufs[id].last, s);
+        }
+        steps.push_back(std::move(fn));
+        n_launches += launches;
+    }
+    float* ptr(const wt::RunCtx& c, int id) const { return reinterpret_cast<float*>(c.ws + bufs[id].off); }
+    void layout() {
+        const bool keep = flags & WT_PLAN_FLAG_KEEP_STAGES;
+        std::vector<int> order(bufs.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return bufs[x].first < bufs[y].first; });
+        std::vector<int> placed;
+        ws_bytes = 0;
+        for (int id : order) {
+            wt::BufSpec& b = bufs[id];
+            if (b.last < 0) { b.off = 0; continue; }
+            if (keep) b.last = INT_MAX;
+            size_t off = 0;
+            bool moved = true;
+            while (moved) {
+                moved = false;
+                for (int pid : placed) {
+                    const wt::BufSpec& q = bufs[pid];
+                    const bool live = !(q.last < b.first || b.last < q.first);
+                    const bool overlap = off < q.off + q.bytes && q.off < off + b.bytes;
+                    if (live && overlap) { off = q.off + q.bytes; moved = true; }
+                }
+            }
+            b.off = off;
+            placed.push_back(id);
+            ws_bytes = std::max(ws_bytes, off + b.bytes);
+        }
+        ws_bytes = std::max<size_t>(ws_bytes, 256);
+    }
+};
+
+namespace wt {
+
+// SConv1d geometry (encoder/modules/conv.py:195-211, 54-61), non-causal.
+struct SConvGeom { int pl, pr_total, Tout, Tp; };
+static SConvGeom sconv_geom(long T, int k, int stride, int dil) {
+    const int keff = (k - 1) * dil + 1;
+    const int pt = keff - stride;
+    const long nfr_num = T - keff + pt;                 // n_frames = nfr_num/stride + 1
+    const long nfr = (nfr_num + stride - 1) / stride + 1;   // ceil (nfr_num >= 0 here since pt = keff - stride)
+    const long ideal = (nfr - 1) * stride + (keff - pt);
+    const int extra = (int)(ideal - T);
+    SConvGeom g;
+    const int pr = pt / 2;
+    g.pl = pt - pr;
+    g.pr_total = pr + extra;
+    g.Tout = (int)((T + pt + extra - keff) / stride + 1);
+    const int maxpad = std::max(g.pl, g.pr_total);
+    g.Tp = T > maxpad ? (int)T : maxpad + 1;
+    return g;
+}
+
+// x [B][T][cin] (time-major) -> y [B][Tout][cout]; reflect-padded SConv1d as one implicit GEMM
+static GemmArgs sconv_args(const ConvW& w, int B, long T, int stride, int dil) {
+    const SConvGeom g = sconv_geom(T, w.k, stride, dil);
+    GemmArgs a;
+    a.a_bstride = T * w.cin; a.a_rstride = w.cin;
+    a.T_in = (int)T; a.T_out = g.Tout; a.Cin = w.cin; a.taps = w.k; a.stride = stride; a.dil = dil;
+    a.pad_left = g.pl; a.pad_mode = PAD_REFLECT; a.Tp = g.Tp;
+    a.W = w.w; a.w_rstride = (long)w.k * w.cin; a.bias = w.b;
+    a.M = B * g.Tout; a.N = w.cout; a.K = w.k * w.cin;
+    a.c_rstride = w.cout;
+    return a;
+}
+// zero-padded 'same' Conv1d (decoder/models.py:29-43,177): k odd, padding (k-1)/2
+static GemmArgs zconv_args(const ConvW& w, int B, int L) {
+    GemmArgs a;
+    a.a_bstride = (long)L * w.cin; a.a_rstride = w.cin;
+    a.T_in = L; a.T_out = L; a.Cin = w.cin; a.taps = w.k; a.pad_left = (w.k - 1) / 2; a.pad_mode = PAD_ZERO;
+    a.W = w.w; a.w_rstride = (long)w.k * w.cin; a.bias = w.b;
+    a.M = B * L; a.N = w.cout; a.K = w.k * w.cin; a.c_rstride = w.cout;
+    return a;
+}
+// plain X[M][K] . W[N][K]^T
+static GemmArgs linear_args(const float* W, const float* bias, long M, int N, int K) {
+    GemmArgs a;
+    a.a_bstride = 0; a.a_rstride = K; a.T_in = (int)M; a.T_out = (int)M; a.Cin = K; a.taps = 1;
+    a.W = W; a.w_rstride = K; a.bias = bias; a.M = (int)M; a.N = N; a.K = K; a.c_rstride = N;
+    return a;
+}
+
+// SEANetResnetBlock (seanet.py:62-63): y = shortcut(x) + conv1(elu(conv3(elu(x)))); returns y's buffer
+static int plan_resblock(wt_plan* P, const ConvW& c3, const ConvW& c1, const ConvW& sc, int B, long T, int xin,
+                         const std::string& name) {
+    const int C = sc.cout;
+    const int h = P->buf(name + ".h", (size_t)B * T * (C / 2));
+    const int y = P->buf(name, (size_t)B * T * C);
+    GemmArgs a3 = sconv_args(c3, B, T, 1, 1);
+    P->step({xin, h}, [=](const RunCtx& c) {
+        GemmArgs a = a3; a.A = P->ptr(c, xin); a.C = P->ptr(c, h);
+        return launch_gemm(a, PRO_ELU, EPI_BIAS, c.stream);
+    });
+    GemmArgs as = sconv_args(sc, B, T, 1, 1);
+    P->step({xin, y}, [=](const RunCtx& c) {
+        GemmArgs a = as; a.A = P->ptr(c, xin); a.C = P->ptr(c, y);
+        return launch_gemm(a, PRO_NONE, EPI_BIAS, c.stream);
+    });
+    GemmArgs a1 = sconv_args(c1, B, T, 1, 1);
+    P->step({h, y}, [=](const RunCtx& c) {
+        GemmArgs a = a1; a.A = P->ptr(c, h); a.C = P->ptr(c, y); a.R = P->ptr(c, y); a.r_rstride = C;
+        return launch_gemm(a, PRO_ELU, EPI_BIAS_RES, c.stream);
+    });
+    return y;
+}
+
+// SLSTM (lstm.py:31-39) on x [B][L][H]; returns y = lstm(x) + x
+static int plan_lstm(wt_plan* P, const LstmW& w, int B, int L, int H, int xin, const std::string& name) {
+    const int xg = P->buf(name + ".xg", (size_t)B * L * 4 * H);
+    const int st = P->buf(name + ".state", (size_t)6 * B * H);   // h0[2], h1[2], c0, c1
+    const int y = P->buf(name, (size_t)B * L * H);
+    GemmArgs ax = linear_args(w.Wih0, w.b0, (long)B * L, 4 * H, H);
+    P->step({xin, xg}, [=](const RunCtx& c) {
+        GemmArgs a = ax; a.A = P->ptr(c, xin); a.C = P->ptr(c, xg);
+        return launch_gemm(a, PRO_NONE, EPI_BIAS, c.stream);
+    });
+    P->step({xin, xg, st, y}, [=](const RunCtx& c) {
+        float* s = P->ptr(c, st);
+        WT_HIP_CHECK(hipMemsetAsync(s, 0, (size_t)6 * B * H * sizeof(float), c.stream));
+        LstmArgs la;
+        la.xg0 = P->ptr(c, xg); la.W0 = w.W0; la.W1 = w.W1; la.b1 = w.b1;
+        la.h0 = s; la.h1 = s + (size_t)2 * B * H; la.c0 = s + (size_t)4 * B * H; la.c1 = s + (size_t)5 * B * H;
+        la.x = P->ptr(c, xin); la.y = P->ptr(c, y); la.B = B; la.L = L; la.H = H;
+        for (int t = 0; t <= L; ++t)
+            if (int rc = launch_lstm_step(la, t, c.stream)) return rc;
+        return 0;
+    }, L + 2);
+    return y;
+}
+
+static int build_encode(wt_plan* P) {
+    const wt_model* M = P->model;
+    const int B = P->B;
+    const long T = P->T;
+    int x = P->buf("enc.0", (size_t)B * T * M->e0_c);
+    P->step({x}, [=](const RunCtx& c) {
+        return launch_conv_first(c.in_f, M->e0_w, M->e0_b, P->ptr(c, x), B, T, M->e0_k, M->e0_c, c.stream);
+    });
+    long Tc = T;
+    int idx = 1;
+    for (const ResStage& st : M->stages) {
+        x = plan_resblock(P, st.c3, st.c1, st.sc, B, Tc, x, "enc." + std::to_string(idx));
+        GemmArgs ad = sconv_args(st.down, B, Tc, st.r, 1);
+        const int y = P->buf("enc." + std::to_string(idx + 2), (size_t)B * ad.T_out * st.down.cout);
+        const int xin = x;
+        P->step({xin, y}, [=](const RunCtx& c) {
+            GemmArgs a = ad; a.A = P->ptr(c, xin); a.C = P->ptr(c, y);
+            return launch_gemm(a, PRO_ELU, EPI_BIAS, c.stream);
+        });
+        x = y; Tc = ad.T_out; idx += 3;
+    }
+    const int L = (int)Tc;
+    if (L != P->L) { set_error("internal: frame count mismatch"); return WT_ERR_INVALID; }
+    const int H = M->H;
+    x = plan_lstm(P, M->enc_lstm, B, L, H, x, "enc." + std::to_string(idx));
+    GemmArgs af = sconv_args(M->enc_final, B, L, 1, 1);
+    const int emb = P->buf("enc." + std::to_string(idx + 2), (size_t)B * L * 512);
+    {
+        const int xin = x;
+        P->step({xin, emb}, [=](const RunCtx& c) {
+            GemmArgs a = af; a.A = P->ptr(c, xin); a.C = P->ptr(c, emb);
+            return launch_gemm(a, PRO_ELU, EPI_BIAS, c.stream);
+        });
+    }
+    // ---- VQ (core_vq.py:175-183, 206-231)
+    const int bins = M->arch.vq_bins;
+    const int np = gemm_vq_parts(bins);
+    const int xx = P->buf("vq.xx", (size_t)B * L);
+    const int pv = P->buf("vq.pval", (size_t)B * L * np);
+    const int pi = P->buf("vq.pidx", (size_t)B * L * np);
+    P->step({emb, xx}, [=](const RunCtx& c) { return launch_row_sumsq(P->ptr(c, emb), P->ptr(c, xx), (long)B * L, 512, c.stream); });
+    GemmArgs av = linear_args(M->embed, nullptr, (long)B * L, bins, 512);
+    P->step({emb, xx, pv, pi}, [=](const RunCtx& c) {
+        GemmArgs a = av; a.A = P->ptr(c, emb);
+        a.vq_xx = P->ptr(c, xx); a.vq_ee = M->ee; a.vq_pval = P->ptr(c, pv);
+        a.vq_pidx = reinterpret_cast<int*>(P->ptr(c, pi)); a.vq_nparts = np;
+        return launch_gemm(a, PRO_NONE, EPI_ARGMAX, c.stream);
+    });
+    P->step({pv, pi, emb}, [=](const RunCtx& c) {
+        if (int rc = launch_vq_finalize(P->ptr(c, pv), reinterpret_cast<int*>(P->ptr(c, pi)), np, M->embed, c.codes,
+                                        c.out_f, B, L, 512, c.stream)) return rc;
+        if (c.aux) return launch_transpose(P->ptr(c, emb), c.aux, B, L, 512, c.stream);
+        return 0;
+    }, 2);
+    return 0;
+}
+
+static int build_decode(wt_plan* P) {
+    const wt_model* M = P->model;
+    const wt_arch& ar = M->arch;
+    const int B = P->B, L = (int)P->L, D = ar.dim, I = ar.intermediate_dim, Cin = ar.input_channels;
+    const long Mrows = (long)B * L;
+    const int Lp = ((L + 31) / 32) * 32;
+    const int x0 = P->buf("bb.in", (size_t)Mrows * Cin);
+    P->step({x0}, [=](const RunCtx& c) { return launch_transpose(c.in_f, P->ptr(c, x0), B, Cin, L, c.stream); });
+    const int x = P->buf("bb.x", (size_t)Mrows * D);       // residual stream, updated in place
+    GemmArgs ae = zconv_args(M->bb_embed, B, L);
+    P->step({x0, x}, [=](const RunCtx& c) {
+        GemmArgs a = ae; a.A = P->ptr(c, x0); a.C = P->ptr(c, x);
+        return launch_gemm(a, PRO_NONE, EPI_BIAS, c.stream);
+    });
+    const bool keep = P->flags & WT_PLAN_FLAG_KEEP_STAGES;
+    auto snapshot = [&](const std::string& name) {   // debug taps of the in-place residual stream
+        if (!keep) return;
+        const int s = P->buf(name, (size_t)Mrows * D);
+        P->step({x, s}, [=](const RunCtx& c) {
+            WT_HIP_CHECK(hipMemcpyAsync(P->ptr(c, s), P->ptr(c, x), (size_t)Mrows * D * sizeof(float), hipMemcpyDeviceToDevice, c.stream));
+            return 0;
+        });
+    };
+    snapshot("bb.embed");
+    const int sc = P->buf("bb.gn_scale", (size_t)B * D), sh = P->buf("bb.gn_shift", (size_t)B * D);
+    const int h1 = P->buf("bb.h1", (size_t)Mrows * D);
+
+    auto resnet = [&](const PosRes& r, const std::string& name) {      // models.py:58-78
+        P->step({x, sc, sh}, [=](const RunCtx& c) {
+            return launch_gn_stats(P->ptr(c, x), r.n1w, r.n1b, P->ptr(c, sc), P->ptr(c, sh), B, L, D, 32, 1e-6f, c.stream);
+        });
+        GemmArgs a1 = zconv_args(r.c1, B, L);
+        P->step({x, sc, sh, h1}, [=](const RunCtx& c) {
+            GemmArgs a = a1; a.A = P->ptr(c, x); a.C = P->ptr(c, h1); a.pro_scale = P->ptr(c, sc); a.pro_shift = P->ptr(c, sh);
+            return launch_gemm(a, PRO_AFFINE_SWISH, EPI_BIAS, c.stream);
+        });
+        P->step({h1, sc, sh}, [=](const RunCtx& c) {
+            return launch_gn_stats(P->ptr(c, h1), r.n2w, r.n2b, P->ptr(c, sc), P->ptr(c, sh), B, L, D, 32, 1e-6f, c.stream);
+        });
+        GemmArgs a2 = zconv_args(r.c2, B, L);
+        P->step({h1, sc, sh, x}, [=](const RunCtx& c) {
+            GemmArgs a = a2; a.A = P->ptr(c, h1); a.C = P->ptr(c, x); a.R = P->ptr(c, x); a.r_rstride = D;
+            a.pro_scale = P->ptr(c, sc); a.pro_shift = P->ptr(c, sh);
+            return launch_gemm(a, PRO_AFFINE_SWISH, EPI_BIAS_RES, c.stream);
+        });
+        snapshot(name);
+    };
+    resnet(M->res[0], "bb.pos_net.0");
+    resnet(M->res[1], "bb.pos_net.1");
+    {   // AttnBlock (models.py:107-127), single head of width D
+        const int qk = P->buf("bb.attn.qk", (size_t)Mrows * 2 * D);
+        const int vt = P->buf("bb.attn.vt", (size_t)B * D * Lp);
+        const int S = P->buf("bb.attn.s", (size_t)Mrows * Lp);
+        const int o = P->buf("bb.attn.o", (size_t)Mrows * D);
+        P->step({x, sc, sh}, [=](const RunCtx& c) {
+            return launch_gn_stats(P->ptr(c, x), M->at_nw, M->at_nb, P->ptr(c, sc), P->ptr(c, sh), B, L, D, 32, 1e-6f, c.stream);
+        });
+        P->step({x, sc, sh, h1}, [=](const RunCtx& c) {
+            return launch_affine(P->ptr(c, x), P->ptr(c, sc), P->ptr(c, sh), P->ptr(c, h1), B, L, D, c.stream);
+        });
+        GemmArgs aqk = linear_args(M->at_Wqk, M->at_bqk, Mrows, 2 * D, D);
+        P->step({h1, qk}, [=](const RunCtx& c) {
+            GemmArgs a = aqk; a.A = P->ptr(c, h1); a.C = P->ptr(c, qk);
+            return launch_gemm(a, PRO_NONE, EPI_BIAS, c.stream);
+        });
+        P->step({h1, vt}, [=](const RunCtx& c) {     // V^T[b] = Wv . hn[b]^T + bv   (D x L, pitch Lp)
+            WT_HIP_CHECK(hipMemsetAsync(P->ptr(c, vt), 0, (size_t)B * D * Lp * sizeof(float), c.stream));
+            GemmArgs a = linear_args(P->ptr(c, h1), M->at_bv, D, L, D);
+            a.A = M->at_Wv; a.zA = 0; a.zW = (long)L * D; a.nz = B;
+            a.C = P->ptr(c, vt); a.c_rstride = Lp; a.zC = (long)D * Lp;
+            return launch_gemm(a, PRO_NONE, EPI_BIAS_ROW, c.stream);
+        }, 2);
+        P->step({qk, S}, [=](const RunCtx& c) {      // S[b] = q[b] . k[b]^T * D^-0.5
+            GemmArgs a = linear_args(P->ptr(c, qk) + D, nullptr, L, L, D);
+            a.A = P->ptr(c, qk); a.a_rstride = 2 * D; a.zA = (long)L * 2 * D;
+            a.w_rstride = 2 * D; a.zW = (long)L * 2 * D; a.nz = B;
+            a.C = P->ptr(c, S); a.c_rstride = Lp; a.zC = (long)L * Lp;
+            a.alpha = (float)std::pow((double)D, -0.5);
+            return launch_gemm(a, PRO_NONE, EPI_SCALE, c.stream);
+        });
+        P->step({S}, [=](const RunCtx& c) { return launch_softmax(P->ptr(c, S), (int)Mrows, L, Lp, c.stream); });
+        P->step({S, vt, o}, [=](const RunCtx& c) {   // O[b] = P[b] . V[b]
+            GemmArgs a = linear_args(P->ptr(c, vt), nullptr, L, D, Lp);
+            a.A = P->ptr(c, S); a.zA = (long)L * Lp; a.zW = (long)D * Lp; a.nz = B;
+            a.C = P->ptr(c, o); a.c_rstride = D; a.zC = (long)L * D;
+            return launch_gemm(a, PRO_NONE, EPI_BIAS, c.stream);
+        });
+        GemmArgs ap = linear_args(M->at_Wp, M->at_bp, Mrows, D, D);
+        P->step({o, x}, [=](const RunCtx& c) {
+            GemmArgs a = ap; a.A = P->ptr(c, o); a.C = P->ptr(c, x); a.R = P->ptr(c, x); a.r_rstride = D;
+            return launch_gemm(a, PRO_NONE, EPI_BIAS_RES, c.stream);
+        });
+        snapshot("bb.pos_net.2");
+    }
+    resnet(M->res[2], "bb.pos_net.3");
+    resnet(M->res[3], "bb.pos_net.4");
+    // pos_net[5] GroupNorm + backbone.norm AdaLayerNorm (models.py:213,228), fused into one row pass
+    const int xc = P->buf(keep ? "bb.x2" : "bb.norm", (size_t)Mrows * D);
+    P->step({x, sc, sh}, [=](const RunCtx& c) {
+        return launch_gn_stats(P->ptr(c, x), M->gn5w, M->gn5b, P->ptr(c, sc), P->ptr(c, sh), B, L, D, 32, 1e-6f, c.stream);
+    });
+    P->step({x, sc, sh, xc}, [=](const RunCtx& c) {
+        return launch_rownorm(RN_AFFINE_IN, P->ptr(c, x), P->ptr(c, xc), B, L, D, nullptr, nullptr, P->ptr(c, sc),
+                              P->ptr(c, sh), M->ada_s + (size_t)c.bw_id * D, M->ada_h + (size_t)c.bw_id * D, 1e-6f, c.stream);
+    });
+    if (keep) {
+        const int sn = P->buf("bb.norm", (size_t)Mrows * D);
+        P->step({xc, sn}, [=](const RunCtx& c) {
+            WT_HIP_CHECK(hipMemcpyAsync(P->ptr(c, sn), P->ptr(c, xc), (size_t)Mrows * D * sizeof(float), hipMemcpyDeviceToDevice, c.stream));
+            return 0;
+        });
+    }
+    // ConvNeXt blocks (modules.py:43-60); xc is the residual stream from here on
+    const int nrm = P->buf("bb.cnx.norm", (size_t)Mrows * D);
+    const int mid = P->buf("bb.cnx.mid", (size_t)Mrows * I);
+    for (int i = 0; i < ar.num_layers; ++i) {
+        const CnxBlock cb = M->cnx[i];
+        P->step({xc, nrm}, [=](const RunCtx& c) {
+            return launch_rownorm(RN_DWCONV, P->ptr(c, xc), P->ptr(c, nrm), B, L, D, cb.dw_w, cb.dw_b, nullptr, nullptr,
+                                  cb.ada_s + (size_t)c.bw_id * D, cb.ada_h + (size_t)c.bw_id * D, 1e-6f, c.stream);
+        });
+        GemmArgs a1 = linear_args(cb.W1, cb.b1, Mrows, I, D);
+        P->step({nrm, mid}, [=](const RunCtx& c) {
+            GemmArgs a = a1; a.A = P->ptr(c, nrm); a.C = P->ptr(c, mid);
+            return launch_gemm(a, PRO_NONE, EPI_BIAS_GELU, c.stream);
+        });
+        GemmArgs a2 = linear_args(cb.W2, cb.b2, Mrows, D, I);
+        P->step({mid, xc}, [=](const RunCtx& c) {
+            GemmArgs a = a2; a.A = P->ptr(c, mid); a.C = P->ptr(c, xc); a.R = P->ptr(c, xc); a.r_rstride = D; a.gamma = cb.gamma;
+            return launch_gemm(a, PRO_NONE, EPI_BIAS_GAMMA_RES, c.stream);
+        });
+        if (keep && (i == 0 || i == ar.num_layers / 2 - 1 || i == ar.num_layers - 1)) {
+            const int s = P->buf("bb.convnext." + std::to_string(i), (size_t)Mrows * D);
+            P->step({xc, s}, [=](const RunCtx& c) {
+                WT_HIP_CHECK(hipMemcpyAsync(P->ptr(c, s), P->ptr(c, xc), (size_t)Mrows * D * sizeof(float), hipMemcpyDeviceToDevice, c.stream));
+                return 0;
+            });
+        }
+    }
+    const int xo = P->buf("bb.out", (size_t)Mrows * D);
+    P->step({xc, xo}, [=](const RunCtx& c) {
+        if (int rc = launch_rownorm(RN_PLAIN, P->ptr(c, xc), P->ptr(c, xo), B, L, D, nullptr, nullptr, nullptr, nullptr,
+                                    M->fln_w, M->fln_b, 1e-6f, c.stream)) return rc;
+        if (c.aux) WT_HIP_CHECK(hipMemcpyAsync(c.aux, P->ptr(c, xo), (size_t)Mrows * D * sizeof(float), hipMemcpyDeviceToDevice, c.stream));
+        return 0;
+    });
+    // ISTFTHead (heads.py:53-66): Linear + exp/clip/cos/sin fused -> spectrum rows [re | im]
+    const int Kb = M->Kb, R = M->R, hop = ar.hop_length;
+    const int spec = P->buf("head.spec", (size_t)Mrows * 2 * Kb);
+    GemmArgs ah = linear_args(M->head_W, M->head_b, Mrows, 2 * Kb, D);
+    P->step({xo, spec}, [=](const RunCtx& c) {
+        GemmArgs a = ah; a.A = P->ptr(c, xo); a.C = P->ptr(c, spec); a.c_rstride = 2 * Kb; a.head_kb = Kb;
+        return launch_gemm(a, PRO_NONE, EPI_HEAD, c.stream);
+    });
+    // ISTFT (spectral_ops.py:56-73): windowed inverse DFT + overlap-add + trim + envelope divide
+    P->step({spec}, [=](const RunCtx& c) {
+        GemmArgs a;
+        a.A = P->ptr(c, spec); a.a_bstride = (long)L * 2 * Kb; a.a_rstride = 2 * Kb;
+        a.T_in = L; a.T_out = L + R - 1; a.Cin = 2 * Kb; a.taps = R; a.pad_left = R - 1; a.pad_mode = PAD_ZERO;
+        a.W = M->istft_W; a.w_rstride = (long)R * 2 * Kb;
+        a.M = B * (L + R - 1); a.N = hop; a.K = R * 2 * Kb;
+        a.C = c.out_f; a.c_rstride = hop;
+        a.ola_L = L; a.ola_hop = hop; a.ola_pad = (ar.n_fft - hop) / 2; a.ola_R = R; a.ola_wsq = M->wsq;
+        return launch_gemm(a, PRO_NONE, EPI_OLA, c.stream);
+    });
+    return 0;
+}
+
+static int build_seanet_decoder(wt_plan* P) {
+    const wt_model* M = P->model;
+    if (!M->has_seadec) { set_error("checkpoint holds no SEANetDecoder weights"); return WT_ERR_MISSING_TENSOR; }
+    const int B = P->B, L = (int)P->L, H = M->H;
+    const int x0 = P->buf("sdec.in", (size_t)B * L * 512);
+    P->step({x0}, [=](const RunCtx& c) { return launch_transpose(c.in_f, P->ptr(c, x0), B, 512, L, c.stream); });
+    int x = P->buf("sdec.0", (size_t)B * L * H);
+    GemmArgs a0 = sconv_args(M->sd_first, B, L, 1, 1);
+    {
+        const int y = x;
+        P->step({x0, y}, [=](const RunCtx& c) {
+            GemmArgs a = a0; a.A = P->ptr(c, x0); a.C = P->ptr(c, y);
+            return launch_gemm(a, PRO_NONE, EPI_BIAS, c.stream);
+        });
+    }
+    x = plan_lstm(P, M->sd_lstm, B, L, H, x, "sdec.1");
+    long Tc = L;
+    int di = 2;
+    for (const SeaDecStage& st : M->sd_stages) {
+        const long To = Tc * st.r;
+        const int y = P->buf("sdec." + std::to_string(di + 1), (size_t)B * To * st.cout);
+        const int xin = x;
+        const int Tin = (int)Tc;
+        P->step({xin, y}, [=](const RunCtx& c) {
+            return launch_convtr(P->ptr(c, xin), st.tr_w, st.tr_b, P->ptr(c, y), B, Tin, st.cin, st.cout, st.k, st.r, 1, c.stream);
+        });
+        x = plan_resblock(P, st.c3, st.c1, st.sc, B, To, y, "sdec." + std::to_string(di + 2));
+        Tc = To; di += 3;
+    }
+    const int xin = x;
+    const long Tf = Tc;
+    P->step({xin}, [=](const RunCtx& c) {
+        return launch_conv_last(P->ptr(c, xin), M->sd_last_w, M->sd_last_b, c.out_f, B, Tf, 32, 7, c.stream);
+    });
+    return 0;
+}
+
+}  // namespace wt
+
+// ================================================================================== C ABI
+using namespace wt;
+
+extern "C" {
+
+const char* wt_last_error(void) { return g_err.c_str(); }
+const char* wt_version(void) { return "wavtokenizer_amd 0.1 (gfx950, fp32 MFMA)"; }
+
+int wt_model_create(const wt_arch* arch, const wt_tensor* tensors, int32_t n_tensors, int32_t device, wt_model** out) {
+    if (!arch || !tensors || !out) { set_error("wt_model_create: null argument"); return WT_ERR_INVALID; }
+    if (arch->n_ratios < 1 || arch->n_ratios > 8) { set_error("n_ratios out of range"); return WT_ERR_INVALID; }
+    if (!arch->padding_same) { set_error("only ISTFT padding='same' is implemented (the mode every reference YAML selects)"); return WT_ERR_INVALID; }
+    if (arch->num_quantizers != 1) { set_error("only num_quantizers=1 is implemented (vq.py:137 forces n_q=1 at inference)"); return WT_ERR_INVALID; }
+    if (arch->input_channels != 512) { set_error("input_channels must be 512 (SEANet dimension)"); return WT_ERR_INVALID; }
+    if (arch->dim % 256 || arch->intermediate_dim % 32) { set_error("dim must be a multiple of 256, intermediate_dim of 32"); return WT_ERR_INVALID; }
+    if (arch->dim % 32 || (arch->dim / 32) % 4) { set_error("dim/32 (GroupNorm group width) must be a multiple of 4"); return WT_ERR_INVALID; }
+    WT_HIP_CHECK(hipSetDevice(device));
+    std::unique_ptr<wt_model> M(new wt_model());
+    M->arch = *arch;
+    M->device = device;
+    M->hop = 1;
+    for (int i = 0; i < arch->n_ratios; ++i) M->hop *= arch->ratios[i];
+    for (int i = arch->n_ratios - 1; i >= 0; --i) M->enc_ratios.push_back(arch->ratios[i]);   // seanet.py:100
+    TensorMap tm;
+    for (int i = 0; i < n_tensors; ++i) tm.m[tensors[i].name] = {tensors[i].data, tensors[i].numel};
+    int rc = build_model(M.get(), tm);
+    if (rc) {
+        if (rc == WT_ERR_MISSING_TENSOR) set_error("state_dict tensor missing or mis-shaped: " + tm.missing);
+        for (void* p : M->allocs) (void)hipFree(p);
+        return rc;
+    }
+    if (int g = gemm_init()) return g;
+    *out = M.release();
+    return WT_OK;
+}
+
+void wt_model_destroy(wt_model* m) {
+    if (!m) return;
+    for (void* p : m->allocs) (void)hipFree(p);
+    delete m;
+}
+int wt_model_hop(const wt_model* m) { return m ? m->hop : 0; }
+int64_t wt_model_weight_bytes(const wt_model* m) { return m ? m->weight_bytes : 0; }
+
+int wt_plan_create(const wt_model* m, int32_t kind, int32_t B, int64_t len, int32_t flags, wt_plan** out) {
+    if (!m || !out) { set_error("wt_plan_create: null argument"); return WT_ERR_INVALID; }
+    if (B < 1 || len < 1) { set_error("wt_plan_create: B and len must be >= 1"); return WT_ERR_INVALID; }
+    if ((len + (kind == WT_PLAN_ENCODE ? m->hop - 1 : 0)) / (kind == WT_PLAN_ENCODE ? m->hop : 1) > 12000) {
+        set_error("clips longer than 12000 frames are not supported by one plan; split the clip"); return WT_ERR_INVALID;
+    }
+    std::unique_ptr<wt_plan> P(new wt_plan());
+    P->model = m; P->kind = kind; P->B = B; P->len = len; P->flags = flags;
+    int rc;
+    if (kind == WT_PLAN_ENCODE) {
+        P->T = len;
+        P->L = (len + m->hop - 1) / m->hop;
+        if ((long)B * len >= (long)INT_MAX) { set_error("batch too large for one plan (32-bit row index)"); return WT_ERR_INVALID; }
+        rc = build_encode(P.get());
+    } else if (kind == WT_PLAN_DECODE) {
+        P->L = len; P->T = len * m->hop;
+        rc = build_decode(P.get());
+    } else if (kind == WT_PLAN_SEANET_DECODER) {
+        P->L = len; P->T = len * m->hop;
+        rc = build_seanet_decoder(P.get());
+    } else {
+        set_error("unknown plan kind"); return WT_ERR_INVALID;
+    }
+    if (rc) return rc;
+    P->layout();
+    *out = P.release();
+    return WT_OK;
+}
+void wt_plan_destroy(wt_plan* p) { delete p; }
+size_t wt_plan_workspace_bytes(const wt_plan* p) { return p ? p->ws_bytes : 0; }
+int64_t wt_plan_frames(const wt_plan* p) { return p ? p->L : 0; }
+int wt_plan_num_launches(const wt_plan* p) { return p ? p->n_launches : 0; }
+
+int wt_plan_find_buffer(const wt_plan* p, const char* name, size_t* offset, size_t* numel) {
+    if (!p || !name) return WT_ERR_INVALID;
+    for (const BufSpec& b : p->bufs)
+        if (b.name == name) {
+            if (offset) *offset = b.off;
+            if (numel) *numel = b.numel;
+            return WT_OK;
+        }
+    set_error(std::string("no stage buffer named ") + name);
+    return WT_ERR_INVALID;
+}
+int wt_plan_buffer_name(const wt_plan* p, int32_t index, const char** name) {
+    if (!p || index < 0 || index >= (int)p->bufs.size()) return WT_ERR_INVALID;
+    *name = p->bufs[index].name.c_str();
+    return WT_OK;
+}
+
+static int run_plan(const wt_plan* p, const RunCtx& c) {
+    WT_HIP_CHECK(hipSetDevice(p->model->device));
+    for (const auto& s : p->steps)
+        if (int rc = s(c)) return rc;
+    return WT_OK;
+}
+
+int wt_encode(const wt_plan* p, const float* wav, float* features, int64_t* codes, float* emb_out, void* workspace,
+              void* stream) {
+    if (!p || p->kind != WT_PLAN_ENCODE) { set_error("wt_encode: not an encode plan"); return WT_ERR_INVALID; }
+    if (!wav || !codes || !workspace) { set_error("wt_encode: null buffer"); return WT_ERR_INVALID; }
+    RunCtx c{static_cast<char*>(workspace), static_cast<hipStream_t>(stream), wav, features, codes, emb_out, 0};
+    return run_plan(p, c);
+}
+
+int wt_decode(const wt_plan* p, const float* features, int32_t bandwidth_id, float* wav_out, float* backbone_out,
+              void* workspace, void* stream) {
+    if (!p || p->kind != WT_PLAN_DECODE) { set_error("wt_decode: not a decode plan"); return WT_ERR_INVALID; }
+    if (!features || !wav_out || !workspace) { set_error("wt_decode: null buffer"); return WT_ERR_INVALID; }
+    if (bandwidth_id < 0 || bandwidth_id >= p->model->arch.adanorm_num_embeddings) {
+        set_error("wt_decode: bandwidth_id out of range"); return WT_ERR_INVALID;
+    }
+    RunCtx c{static_cast<char*>(workspace), static_cast<hipStream_t>(stream), features, wav_out, nullptr, backbone_out, bandwidth_id};
+    return run_plan(p, c);
+}
+
+int wt_seanet_decode(const wt_plan* p, const float* features, float* wav_out, void* workspace, void* stream) {
+    if (!p || p->kind != WT_PLAN_SEANET_DECODER) { set_error("wt_seanet_decode: wrong plan kind"); return WT_ERR_INVALID; }
+    if (!features || !wav_out || !workspace) { set_error("wt_seanet_decode: null buffer"); return WT_ERR_INVALID; }
+    RunCtx c{static_cast<char*>(workspace), static_cast<hipStream_t>(stream), features, wav_out, nullptr, nullptr, 0};
+    return run_plan(p, c);
+}
+
+int wt_codes_to_features(const wt_model* m, const int64_t* codes, int32_t K, int32_t B, int64_t L, float* features,
+                         void* stream) {
+    if (!m || !codes || !features) { set_error("wt_codes_to_features: null argument"); return WT_ERR_INVALID; }
+    if (K < 1 || K > m->arch.num_quantizers) { set_error("wt_codes_to_features: K exceeds the number of codebooks"); return WT_ERR_INVALID; }
+    WT_HIP_CHECK(hipSetDevice(m->device));
+    return launch_codes_to_features(codes, m->embed, K, m->arch.vq_bins, B, L, 512, features, static_cast<hipStream_t>(stream));
+}
+
+int wt_sconv1d(const float* x, const float* w, const float* bias, float* y, int32_t B, int64_t T, int32_t Cin,
+               int32_t Cout, int32_t k, int32_t stride, int32_t dilation, int32_t elu_input, void* stream) {
+    ConvW cw; cw.w = const_cast<float*>(w); cw.b = const_cast<float*>(bias); cw.cout = Cout; cw.cin = Cin; cw.k = k;
+    GemmArgs a = sconv_args(cw, B, T, stride, dilation);
+    a.A = x; a.C = y;
+    return launch_gemm(a, elu_input ? PRO_ELU : PRO_NONE, EPI_BIAS, static_cast<hipStream_t>(stream));
+}
+
+size_t wt_vq_workspace_bytes(int64_t N, int32_t bins) {
+    const size_t np = gemm_vq_parts(bins);
+    return ((size_t)N * sizeof(float) + 255) / 256 * 256 + 2 * (((size_t)N * np * sizeof(float) + 255) / 256 * 256) +
+           (size_t)bins * sizeof(float) + 256;
+}
+
+// the ee[] table here is rebuilt per call on the device by row_sumsq (same kernel as |x|^2)
+int wt_vq_nearest(const float* x, const float* embed, int64_t N, int32_t D, int32_t bins, int64_t* codes_out,
+                  void* workspace, void* stream) {
+    if (!x || !embed || !codes_out || !workspace) { set_error("wt_vq_nearest: null argument"); return WT_ERR_INVALID; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int np = gemm_vq_parts(bins);
+    char* ws = static_cast<char*>(workspace);
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    float* xx = reinterpret_cast<float*>(ws); ws += al((size_t)N * sizeof(float));
+    float* pv = reinterpret_cast<float*>(ws); ws += al((size_t)N * np * sizeof(float));
+    int* pi = reinterpret_cast<int*>(ws); ws += al((size_t)N * np * sizeof(float));
+    float* ee = reinterpret_cast<float*>(ws);
+    if (int rc = launch_row_sumsq(x, xx, N, D, s)) return rc;
+    if (int rc = launch_row_sumsq(embed, ee, bins, D, s)) return rc;
+    GemmArgs a = linear_args(embed, nullptr, N, bins, D);
+    a.A = x; a.vq_xx = xx; a.vq_ee = ee; a.vq_pval = pv; a.vq_pidx = pi; a.vq_nparts = np;
+    if (int rc = launch_gemm(a, PRO_NONE, EPI_ARGMAX, s)) return rc;
+    for (int64_t r0 = 0; r0 < N; r0 += 8192) {      // finalize keeps one chunk of codes in LDS
+        const int n = (int)std::min<int64_t>(8192, N - r0);
+        if (int rc = launch_vq_finalize(pv + r0 * np, pi + r0 * np, np, embed, codes_out + r0, nullptr, 1, n, D, s)) return rc;
+    }
+    return WT_OK;
+}
+
+}  // extern "C"

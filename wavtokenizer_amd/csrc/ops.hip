@@ -1,0 +1,567 @@
+// The non-GEMM kernels of the WavTokenizer path (gfx950): all HBM/L2-bound, 64-lane waves,
+// 16-byte accesses along the contiguous channel axis of the time-major layout.
+#include "common.h"
+
+namespace wt {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ int reflect_pos(int pos, int T, int Tp, bool& ok) {
+    // encoder/modules/conv.py:79-96: reflect about 0 and Tp-1 (Tp > T only for inputs shorter
+    // than the pad, which the reference zero-extends first)
+    if (pos < 0) pos = -pos;
+    if (pos >= Tp) pos = 2 * (Tp - 1) - pos;
+    ok = pos < T;
+    return pos;
+}
+
+// ------------------------------------------------------------------ first encoder conv (Cin = 1)
+// SEANetEncoder model[0]: SConv1d(1, 32, k=7) (encoder/modules/seanet.py:107-110), reflect pad.
+// wav [B][T] -> y [B][T][Cout]; one thread = one frame x 4 output channels (16-B store).
+__global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ wav, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y,
+                                                         long BT, int T, int k, int Cout, int Tp) {
+    const int c4n = Cout >> 2;
+    const long total = BT * c4n;
+    const int pl = (k - 1) - (k - 1) / 2;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long m = idx / c4n;
+        const int c = (int)(idx - m * c4n) * 4;
+        const long b = m / T;
+        const int t = (int)(m - b * T);
+        f32x4 acc = *reinterpret_cast<const f32x4*>(bias + c);
+        const float* x = wav + b * T;
+        for (int j = 0; j < k; ++j) {
+            bool ok;
+            const int pos = reflect_pos(t + j - pl, T, Tp, ok);
+            const float xv = ok ? x[pos] : 0.f;
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + j * Cout + c);
+            acc += xv * wv;
+        }
+        *reinterpret_cast<f32x4*>(y + m * Cout + c) = acc;
+    }
+}
+
+int launch_conv_first(const float* wav, const float* w, const float* bias, float* y, int B, long T, int k, int Cout,
+                      hipStream_t s) {
+    const long BT = (long)B * T;
+    const int pl = (k - 1) - (k - 1) / 2, pr = (k - 1) / 2;
+    const int maxpad = pl > pr ? pl : pr;
+    const int Tp = T > maxpad ? (int)T : maxpad + 1;
+    long total = BT * (Cout / 4);
+    int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(conv_first_kernel, dim3(blocks), dim3(256), 0, s, wav, w, bias, y, BT, (int)T, k, Cout, Tp);
+    WT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ----------------------------------------------------------- last SEANetDecoder conv (Cout = 1)
+// SEANetDecoder final SConv1d(32, 1, k=7) (seanet.py:223-226) with ELU on its input (:222).
+__global__ __launch_bounds__(256) void conv_last_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y,
+                                                        long BT, int T, int Cin, int k, int Tp) {
+    const int pl = (k - 1) - (k - 1) / 2;
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < BT; m += (long)gridDim.x * blockDim.x) {
+        const long b = m / T;
+        const int t = (int)(m - b * T);
+        float acc = bias[0];
+        for (int j = 0; j < k; ++j) {
+            bool ok;
+            const int pos = reflect_pos(t + j - pl, T, Tp, ok);
+            if (!ok) continue;
+            const float* xr = x + (b * T + pos) * Cin;
+            for (int c = 0; c < Cin; c += 4) {
+                f32x4 xv = *reinterpret_cast<const f32x4*>(xr + c);
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w + j * Cin + c);
+                xv.x = xv.x > 0.f ? xv.x : expm1f(xv.x);
+                xv.y = xv.y > 0.f ? xv.y : expm1f(xv.y);
+                xv.z = xv.z > 0.f ? xv.z : expm1f(xv.z);
+                xv.w = xv.w > 0.f ? xv.w : expm1f(xv.w);
+                acc += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+            }
+        }
+        y[m] = acc;
+    }
+}
+
+int launch_conv_last(const float* x, const float* w, const float* bias, float* y, int B, long T, int Cin, int k,
+                     hipStream_t s) {
+    const long BT = (long)B * T;
+    const int pl = (k - 1) - (k - 1) / 2, pr = (k - 1) / 2;
+    const int maxpad = pl > pr ? pl : pr;
+    const int Tp = T > maxpad ? (int)T : maxpad + 1;
+    int blocks = (int)((BT + 255) / 256 < 16384 ? (BT + 255) / 256 : 16384);
+    hipLaunchKernelGGL(conv_last_kernel, dim3(blocks), dim3(256), 0, s, x, w, bias, y, BT, (int)T, Cin, k, Tp);
+    WT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ transpose
+// [B][R][C] -> [B][C][R] through a padded 32x32 LDS tile (coalesced on both sides).
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R,
+                                                        int C) {
+    __shared__ float tile[32][33];
+    const long boff = (long)blockIdx.z * R * C;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        if (r < R && c < C) tile[i][tx] = in[boff + (long)r * C + c];
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (r < R && c < C) out[boff + (long)c * R + r] = tile[tx][i];
+    }
+}
+
+int launch_transpose(const float* in, float* out, int B, int R, int C, hipStream_t s) {
+    dim3 grid((C + 31) / 32, (R + 31) / 32, B);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, in, out, R, C);
+    WT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- GroupNorm statistics
+// decoder/models.py:15-16 Normalize = GroupNorm(32, C, eps=1e-6, affine): per (clip, group) mean and
+// biased variance over L x C/32 values, emitted as the per-(clip, channel) scale/shift
+//   y = x * (rstd*gamma[c]) + (beta[c] - mean*rstd*gamma[c])
+// that the consuming GEMM applies while staging its A operand (never a normalised copy in HBM).
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ scale,
+                                                       float* __restrict__ shift, int L, int C, int cg, float eps) {
+    __shared__ float red[4];
+    __shared__ float s_mean, s_rstd;
+    const int g = blockIdx.x, b = blockIdx.y;
+    const float* xb = x + (long)b * L * C + g * cg;
+    const int n = L * cg;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float sum = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int t = i / cg, j = i - t * cg;
+        sum += xb[(long)t * C + j];
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wv] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) s_mean = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+    __syncthreads();
+    const float mean = s_mean;
+    float sq = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int t = i / cg, j = i - t * cg;
+        const float d = xb[(long)t * C + j] - mean;
+        sq += d * d;
+    }
+    sq = wave_sum(sq);
+    __syncthreads();
+    if (lane == 0) red[wv] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) s_rstd = 1.f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)n + eps);
+    __syncthreads();
+    if (threadIdx.x < cg) {
+        const int c = g * cg + threadIdx.x;
+        const float sc = s_rstd * gamma[c];
+        scale[(long)b * C + c] = sc;
+        shift[(long)b * C + c] = beta[c] - mean * sc;
+    }
+}
+
+int launch_gn_stats(const float* x, const float* gamma, const float* beta, float* scale, float* shift, int B, int L,
+                    int C, int groups, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(groups, B), dim3(256), 0, s, x, gamma, beta, scale, shift, L, C,
+                       C / groups, eps);
+    WT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void affine_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, float* __restrict__ y, long n4,
+                                                     int LC4, int C4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / LC4;
+        const int c4 = (int)(i % C4);
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[b * C4 + c4];
+        const f32x4 sh = reinterpret_cast<const f32x4*>(shift)[b * C4 + c4];
+        reinterpret_cast<f32x4*>(y)[i] = v * sc + sh;
+    }
+}
+
+int launch_affine(const float* x, const float* scale, const float* shift, float* y, int B, int L, int C,
+                  hipStream_t s) {
+    const long n4 = (long)B * L * C / 4;
+    int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(affine_kernel, dim3(blocks), dim3(256), 0, s, x, scale, shift, y, n4, L * C / 4, C / 4);
+    WT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ row LayerNorm (+ dwconv / affine)
+// One wave per frame row of C = NV*256 channels:
+//   RN_DWCONV   : ConvNeXtBlock dwconv k7 p3 groups=C (decoder/modules.py:28,45) then AdaLayerNorm
+//                 (modules.py:81-86): LN(no affine, eps) * scale[id] + shift[id]
+//   RN_PLAIN    : final_layer_norm (decoder/models.py:195,234)
+//   RN_AFFINE_IN: pos_net[5] GroupNorm apply (models.py:213) then backbone AdaLayerNorm (:228)
+template <int NV, int MODE>
+__global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ x, float* __restrict__ y, long M, int L,
+                                                      const float* __restrict__ dw_w, const float* __restrict__ dw_b,
+                                                      const float* __restrict__ in_scale,
+                                                      const float* __restrict__ in_shift,
+                                                      const float* __restrict__ out_scale,
+                                                      const float* __restrict__ out_shift, float eps) {
+    constexpr int C = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const long b = m / L;
+    const int t = (int)(m - b * L);
+    f32x4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (MODE == RN_DWCONV) {
+            f32x4 acc = *reinterpret_cast<const f32x4*>(dw_b + c);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int tt = t + j - 3;
+                if (tt >= 0 && tt < L) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (b * L + tt) * C + c);
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(dw_w + j * C + c);
+                    acc += xv * wv;
+                }
+            }
+            v[i] = acc;
+        } else {
+            f32x4 xv = *reinterpret_cast<const f32x4*>(x + m * C + c);
+            if (MODE == RN_AFFINE_IN) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(in_scale + b * C + c);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(in_shift + b * C + c);
+                xv = xv * sc + sh;
+            }
+            v[i] = xv;
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    const float mean = wave_sum(sum) * (1.f / C);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const f32x4 d = v[i] - mean;
+        sq += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+    }
+    const float rstd = 1.f / sqrtf(wave_sum(sq) * (1.f / C) + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        const f32x4 os = *reinterpret_cast<const f32x4*>(out_scale + c);
+        const f32x4 oh = *reinterpret_cast<const f32x4*>(out_shift + c);
+        *reinterpret_cast<f32x4*>(y + m * C + c) = ((v[i] - mean) * rstd) * os + oh;
+    }
+}
+
+template <int NV>
+static int launch_rownorm_nv(int mode, const float* x, float* y, long M, int L, const float* dw_w, const float* dw_b,
+                             const float* is, const float* ih, const float* os, const float* oh, float eps,
+                             hipStream_t s) {
+    dim3 grid((unsigned)((M + 3) / 4));
+    if (mode == RN_DWCONV)
+        hipLaunchKernelGGL((rownorm_kernel<NV, RN_DWCONV>), grid, dim3(256), 0, s, x, y, M, L, dw_w, dw_b, is, ih, os, oh, eps);
+    else if (mode == RN_PLAIN)
+        hipLaunchKernelGGL((rownorm_kernel<NV, RN_PLAIN>), grid, dim3(256), 0, s, x, y, M, L, dw_w, dw_b, is, ih, os, oh, eps);
+    else
+        hipLaunchKernelGGL((rownorm_kernel<NV, RN_AFFINE_IN>), grid, dim3(256), 0, s, x, y, M, L, dw_w, dw_b, is, ih, os, oh, eps);
+    WT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_rownorm(int mode, const float* x, float* y, int B, int L, int C, const float* dw_w, const float* dw_b,
+                   const float* in_scale, const float* in_shift, const float* out_scale, const float* out_shift,
+                   float eps, hipStream_t s) {
+    const long M = (long)B * L;
+    switch (C) {
+        case 256: return launch_rownorm_nv<1>(mode, x, y, M, L, dw_w, dw_b, in_scale, in_shift, out_scale, out_shift, eps, s);
+        case 512: return launch_rownorm_nv<2>(mode, x, y, M, L, dw_w, dw_b, in_scale, in_shift, out_scale, out_shift, eps, s);
+        case 768: return launch_rownorm_nv<3>(mode, x, y, M, L, dw_w, dw_b, in_scale, in_shift, out_scale, out_shift, eps, s);
+        case 1024: return launch_rownorm_nv<4>(mode, x, y, M, L, dw_w, dw_b, in_scale, in_shift, out_scale, out_shift, eps, s);
+        default: set_error("rownorm: backbone dim must be 256, 512, 768 or 1024"); return -1;
+    }
+}
+
+// -------------------------------------------------------------------------------------- softmax
+// AttnBlock softmax over keys (decoder/models.py:119); one wave per query row; pad columns
+// [L, ld) are zero-filled so the P.V contraction can run over the padded length.
+__global__ __launch_bounds__(256) void softmax_kernel(float* __restrict__ S, long rows, int L, int ld) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float* row = S + r * ld;
+    float mx = -INFINITY;
+    for (int j = lane; j < L; j += 64) mx = fmaxf(mx, row[j]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < L; j += 64) {
+        const float e = expf(row[j] - mx);
+        row[j] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    for (int j = lane; j < ld; j += 64) row[j] = j < L ? row[j] / sum : 0.f;
+}
+
+int launch_softmax(float* S, int rows, int L, int ld, hipStream_t s) {
+    hipLaunchKernelGGL(softmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, S, (long)rows, L, ld);
+    WT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ----------------------------------------------------------------------------------------- VQ
+__global__ __launch_bounds__(256) void row_sumsq_kernel(const float* __restrict__ x, float* __restrict__ out, long rows,
+                                                        int D) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float s = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * D + c);
+        s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[r] = s;
+}
+
+int launch_row_sumsq(const float* x, float* out, long rows, int D, hipStream_t s) {
+    hipLaunchKernelGGL(row_sumsq_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, out, rows, D);
+    WT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// Reduce the per-column-slab (value, index) partials in slab order (strict '>' keeps the lowest
+// index on ties, like torch.max), write int64 codes and — if feat != null — the dequantised
+// embedding in the reference's (B, D, L) layout (core_vq.py:188-190 + rearrange b n d -> b d n).
+__global__ __launch_bounds__(256) void vq_finalize_kernel(const float* __restrict__ pval, const int* __restrict__ pidx,
+                                                          int nparts, const float* __restrict__ embed,
+                                                          int64_t* __restrict__ codes, float* __restrict__ feat, int L,
+                                                          int D, int cchunk) {
+    extern __shared__ int s_code[];
+    const int b = blockIdx.x;
+    for (int t = threadIdx.x; t < L; t += 256) {
+        const long m = (long)b * L + t;
+        float best = pval[m * nparts];
+        int bi = pidx[m * nparts];
+        for (int q = 1; q < nparts; ++q) {
+            const float v = pval[m * nparts + q];
+            if (v > best) { best = v; bi = pidx[m * nparts + q]; }
+        }
+        s_code[t] = bi;
+        if (blockIdx.y == 0) codes[m] = (int64_t)bi;
+    }
+    __syncthreads();
+    if (feat == nullptr) return;
+    const int c0 = blockIdx.y * cchunk;
+    const int n = cchunk * L;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int c = c0 + i / L, t = i % L;
+        if (c < D) feat[((long)b * D + c) * L + t] = embed[(long)s_code[t] * D + c];
+    }
+}
+
+int launch_vq_finalize(const float* pval, const int* pidx, int nparts, const float* embed, int64_t* codes,
+                       float* feat_ncl, int B, int L, int D, hipStream_t s) {
+    const int cchunk = 64;
+    dim3 grid(B, feat_ncl ? (D + cchunk - 1) / cchunk : 1);
+    hipLaunchKernelGGL(vq_finalize_kernel, grid, dim3(256), (size_t)L * sizeof(int), s, pval, pidx, nparts, embed,
+                       codes, feat_ncl, L, D, cchunk);
+    WT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// WavTokenizer.codes_to_features (decoder/pretrained.py:227-237): sum over the K codebooks of
+// embed[codes[k] + k*bins], transposed to (B, D, L).  Out-of-range codes are clamped.
+__global__ __launch_bounds__(256) void codes_to_features_kernel(const int64_t* __restrict__ codes,
+                                                                const float* __restrict__ embed, int K, int bins,
+                                                                long L, int D, float* __restrict__ feat, int cchunk) {
+    const int b = blockIdx.x, B = gridDim.x;
+    const int c0 = blockIdx.y * cchunk;
+    const long t0 = (long)blockIdx.z * 1024;
+    const long tn = (L - t0) < 1024 ? (L - t0) : 1024;
+    const long n = (long)cchunk * tn;
+    for (long i = threadIdx.x; i < n; i += 256) {
+        const int c = c0 + (int)(i / tn);
+        const long t = t0 + i % tn;
+        if (c >= D) continue;
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) {
+            long code = codes[((long)k * B + b) * L + t];
+            code = code < 0 ? 0 : (code >= bins ? bins - 1 : code);
+            acc += embed[((long)k * bins + code) * D + c];
+        }
+        feat[((long)b * D + c) * L + t] = acc;
+    }
+}
+
+int launch_codes_to_features(const int64_t* codes, const float* embed, int K, int bins, int B, long L, int D,
+                             float* feat_ncl, hipStream_t s) {
+    const int cchunk = 64;
+    dim3 grid(B, (D + cchunk - 1) / cchunk, (unsigned)((L + 1023) / 1024));
+    hipLaunchKernelGGL(codes_to_features_kernel, grid, dim3(256), 0, s, codes, embed, K, bins, L, D, feat_ncl, cchunk);
+    WT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------- LSTM
+// SLSTM (encoder/modules/lstm.py:12-39): nn.LSTM(512, 512, num_layers=2), zero initial state, gate
+// order i,f,g,o, plus the skip add.  The recurrence is serial in time, so one launch = one
+// time step of BOTH layers, layer 1 running one step behind layer 0 (launch s: layer 0 step s,
+// layer 1 step s-1).  A workgroup owns 4 hidden units (their 16 gate rows, packed contiguously
+// at load time) for a tile of 64 clips; its 4 waves split K, v_mfma_f32_16x16x4_f32 does the
+// recurrent product, LDS adds the four K slices, and each thread then updates one (clip, unit)
+// cell.  Weights stream from L2/Infinity Cache (4-8 MB per layer), h ping-pongs in HBM.
+typedef float f32x4acc __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void lstm_step_kernel(const LstmArgs a, int s) {
+    __shared__ float red[4][64][17];
+    const int H = a.H, B = a.B, L = a.L;
+    const int nj = H / 4;
+    const int layer = blockIdx.x >= nj ? 1 : 0;
+    const int bj = blockIdx.x - layer * nj;
+    const int t = s - layer;                        // time step this block advances
+    if (t < 0 || t >= L) return;                    // uniform per block
+    const int b0 = blockIdx.y * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+
+    const int Ktot = layer ? 2 * H : H;
+    const int kw = Ktot / 4;                        // K slice of this wave
+    const int kbeg = wave * kw;
+    const float* W = (layer ? a.W1 : a.W0) + (long)(bj * 16 + li) * Ktot;
+    // source of the K slice: layer 0: h0[t-1]; layer 1: [h0[t] | h1[t-1]]
+    const float* hsrc;
+    int koff;                                       // column offset inside hsrc rows
+    if (!layer) { hsrc = a.h0 + (long)((t + 1) & 1) * B * H; koff = kbeg; }
+    else if (kbeg < H) { hsrc = a.h0 + (long)(t & 1) * B * H; koff = kbeg; }
+    else { hsrc = a.h1 + (long)((t + 1) & 1) * B * H; koff = kbeg - H; }
+
+    f32x4acc acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (f32x4acc){0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < kw; k += 16) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(W + kbeg + k + 4 * lk);
+        f32x4 hv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int bb = b0 + i * 16 + li;
+            hv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (bb < B) hv[i] = *reinterpret_cast<const f32x4*>(hsrc + (long)bb * H + koff + k + 4 * lk);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[i][e], wv[e], acc[i], 0, 0, 0);
+    }
+    // C layout 16x16: col = lane & 15 (gate row), row = 4*(lane>>4) + reg (clip)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][i * 16 + 4 * lk + r][li] = acc[i][r];
+    __syncthreads();
+
+    const int br = threadIdx.x >> 2, jj = threadIdx.x & 3;
+    const int bb = b0 + br;
+    if (bb >= B) return;
+    const int j = bj * 4 + jj;
+    float g4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int col = g * 4 + jj;
+        float v = (red[0][br][col] + red[1][br][col]) + (red[2][br][col] + red[3][br][col]);
+        if (!layer) v += a.xg0[((long)bb * L + t) * (4 * H) + bj * 16 + col];
+        else v += a.b1[bj * 16 + col];
+        g4[g] = v;
+    }
+    float* cst = (layer ? a.c1 : a.c0) + (long)bb * H + j;
+    const float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]), gg = tanhf(g4[2]), og = sigmoidf_(g4[3]);
+    const float c = fg * (*cst) + ig * gg;
+    const float h = og * tanhf(c);
+    *cst = c;
+    if (!layer) {
+        a.h0[(long)(t & 1) * B * H + (long)bb * H + j] = h;
+    } else {
+        a.h1[(long)(t & 1) * B * H + (long)bb * H + j] = h;
+        const long o = ((long)bb * L + t) * H + j;
+        a.y[o] = h + a.x[o];                        // lstm.py:37-38 skip
+    }
+}
+
+int launch_lstm_step(const LstmArgs& a, int s, hipStream_t stream) {
+    dim3 grid(2 * (a.H / 4), (a.B + 63) / 64);
+    hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(256), 0, stream, a, s);
+    WT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------- ConvTranspose1d
+// SConvTranspose1d (encoder/modules/conv.py:232-253), time-major: y[b][u][co] = bias[co] +
+// sum over (t, j) with t*stride + j - trim_left == u of elu(x[b][t][ci]) * w[j][ci][co].
+// With k = 2*stride every output sample has exactly two contributing input frames.
+__global__ __launch_bounds__(256) void convtr_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ y, long total,
+                                                     int Tin, int Tout, int Cin, int Cout, int k, int stride, int trim_l,
+                                                     int elu_in) {
+    const int c4n = Cout >> 2;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long m = idx / c4n;
+        const int co = (int)(idx - m * c4n) * 4;
+        const long b = m / Tout;
+        const int u = (int)(m - b * Tout) + trim_l;     // position in the untrimmed output
+        f32x4 acc = *reinterpret_cast<const f32x4*>(bias + co);
+        // t ranges over frames with 0 <= u - t*stride < k
+        int t_hi = u / stride;
+        if (t_hi > Tin - 1) t_hi = Tin - 1;
+        int t_lo = (u - k + stride) / stride;
+        if (u - k + 1 <= 0) t_lo = 0;
+        if (t_lo < 0) t_lo = 0;
+        for (int t = t_lo; t <= t_hi; ++t) {
+            const int j = u - t * stride;
+            if (j < 0 || j >= k) continue;
+            const float* xr = x + (b * Tin + t) * Cin;
+            const float* wr = w + ((long)j * Cin) * Cout + co;
+            for (int ci = 0; ci < Cin; ++ci) {
+                float xv = xr[ci];
+                if (elu_in) xv = xv > 0.f ? xv : expm1f(xv);
+                acc += xv * *reinterpret_cast<const f32x4*>(wr + (long)ci * Cout);
+            }
+        }
+        *reinterpret_cast<f32x4*>(y + m * Cout + co) = acc;
+    }
+}
+
+int launch_convtr(const float* x, const float* w, const float* bias, float* y, int B, int Tin, int Cin, int Cout,
+                  int k, int stride, int elu_in, hipStream_t s) {
+    const int pad_total = k - stride;
+    const int pr = pad_total / 2, pl = pad_total - pr;
+    const int Tout = (Tin - 1) * stride + k - pad_total;    // = Tin*stride
+    const long total = (long)B * Tout * (Cout / 4);
+    int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(convtr_kernel, dim3(blocks), dim3(256), 0, s, x, w, bias, y, total, Tin, Tout, Cin, Cout, k,
+                       stride, pl, elu_in);
+    WT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace wt

@@ -1,0 +1,439 @@
+"""Drop-in ``WavTokenizer`` (mirror of the reference's decoder/pretrained.py:32-239).
+
+Same constructor classmethods, method names, argument meaning, tensor layouts and error
+behaviour as the reference class; underneath, every method enqueues hand-written HIP kernels
+through the C-ABI library (``include/wavtokenizer_amd.h``).  PyTorch supplies device memory,
+the current HIP stream and the ``nn.Module`` parameter container (so ``state_dict()`` /
+``load_state_dict()`` / ``.to(device)`` keep working with reference checkpoints) — no torch op
+runs on the compute path, and there is no CPU fallback: calling a method while the module sits
+on the CPU raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import weakref
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import yaml
+from torch import nn
+
+from . import _capi
+from ._capi import WavTokError, WtArch, WtTensor, check, lib
+from .config import ArchConfig, arch_from_yaml_dict
+from .state_spec import full_state_spec, is_buffer
+
+
+# ------------------------------------------------------------------ parameter containers
+class _Holder(nn.Module):
+    """Parameter/buffer container addressed by the reference's dotted state-dict keys."""
+
+    def _put(self, dotted: str, tensor: torch.Tensor, buffer: bool):
+        head, _, rest = dotted.partition(".")
+        if rest:
+            if head not in self._modules:
+                self.add_module(head, _Holder())
+            self._modules[head]._put(rest, tensor, buffer)
+        elif buffer:
+            self.register_buffer(head, tensor)
+        else:
+            self.register_parameter(head, nn.Parameter(tensor, requires_grad=False))
+
+    def __getitem__(self, i):
+        return self._modules[str(i)]
+
+    def __len__(self):
+        return len(self._modules)
+
+    def __iter__(self):
+        return iter(self._modules.values())
+
+    def _bind(self, root):
+        object.__setattr__(self, "_root", weakref.ref(root))
+        for m in self._modules.values():
+            if isinstance(m, _Holder):
+                m._bind(root)
+
+
+class SEANetEncoder(_Holder):
+    """encodec.encoder: callable (B,1,T) -> (B,512,L) (encoder/modules/seanet.py:143)."""
+
+    @torch.inference_mode()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        assert x.dim() == 3 and x.shape[1] == 1, "expected (B, 1, T)"
+        return self._root()._run_encode(x[:, 0, :])[2]
+
+
+class SEANetDecoder(_Holder):
+    """encodec.decoder: callable (B,512,L) -> (B,1,L*hop) (encoder/modules/seanet.py:236-238)."""
+
+    @torch.inference_mode()
+    def forward(self, z: torch.Tensor) -> torch.Tensor:
+        return self._root()._run_seanet_decoder(z)
+
+
+class _CodebookLayer(_Holder):
+    @property
+    def codebook(self):                 # core_vq.py:274-276
+        return self._modules["_codebook"].embed
+
+
+class ResidualVectorQuantizer(_Holder):
+    pass
+
+
+class EncodecModel(_Holder):
+    sample_rate = 24000
+    channels = 1
+
+
+class EncodecFeatures(_Holder):
+    """decoder/feature_extractors.py:55-142 (container + infer)."""
+
+    def forward(self, audio: torch.Tensor, bandwidth_id: torch.Tensor):
+        # eval-mode quantiser forward picks n_q = 1 as well (vq.py:98-111), so it equals infer()
+        return self.infer(audio, bandwidth_id)
+
+    @torch.inference_mode()
+    def infer(self, audio: torch.Tensor, bandwidth_id: torch.Tensor):
+        _ = self.bandwidths[int(bandwidth_id.reshape(-1)[0])] if bandwidth_id is not None else None
+        feats, codes, _emb = self._root()._run_encode(audio, want_emb=False)
+        commit_loss = torch.zeros((), device=audio.device)
+        return feats, codes, commit_loss
+
+
+class VocosBackbone(_Holder):
+    """decoder/models.py:223-235: callable (B,512,L) -> (B,L,dim)."""
+
+    @torch.inference_mode()
+    def forward(self, x: torch.Tensor, bandwidth_id: Optional[torch.Tensor] = None) -> torch.Tensor:
+        assert bandwidth_id is not None      # models.py:227
+        return self._root()._run_decode(x, bandwidth_id, want_backbone=True)[1]
+
+
+class ISTFTHead(_Holder):
+    def forward(self, x):
+        raise NotImplementedError("head is fused with the backbone in WavTokenizer.decode; call decode()")
+
+
+def _build_tree(arch: ArchConfig) -> Tuple[EncodecFeatures, VocosBackbone, ISTFTHead]:
+    fe, bb, hd = EncodecFeatures(), VocosBackbone(), ISTFTHead()
+    enc_model = EncodecModel()
+    enc_model.add_module("encoder", SEANetEncoder())
+    enc_model.add_module("quantizer", ResidualVectorQuantizer())
+    enc_model.add_module("decoder", SEANetDecoder())
+    fe.add_module("encodec", enc_model)
+    q = enc_model.quantizer
+    q.add_module("vq", _Holder())
+    q.vq.add_module("layers", _Holder())
+    for i in range(arch.num_quantizers):
+        q.vq.layers.add_module(str(i), _CodebookLayer())
+    q.bins = arch.vq_bins
+    q.n_q = arch.num_quantizers
+    q.dimension = 512
+    fe.bandwidths = list(arch.bandwidths)
+    fe.frame_rate = 25
+    roots = {"feature_extractor": fe, "backbone": bb, "head": hd}
+    for key, shape in full_state_spec(arch).items():
+        top, _, rest = key.partition(".")
+        t = torch.zeros(shape, dtype=torch.float32)
+        roots[top]._put(rest, t, is_buffer(key))
+    return fe, bb, hd
+
+
+# --------------------------------------------------------------------------------- engine
+class _Engine:
+    """Owns the wt_model handle, the (kind, B, len) plans and their workspaces."""
+
+    def __init__(self):
+        self.model = ctypes.c_void_p()
+        self.plans: Dict[Tuple[int, int, int, int], Tuple[ctypes.c_void_p, torch.Tensor]] = {}
+        self.device_index = -1
+        self._keepalive: List[Any] = []
+
+    def close(self):
+        for plan, _ws in self.plans.values():
+            lib.wt_plan_destroy(plan)
+        self.plans.clear()
+        if self.model:
+            lib.wt_model_destroy(self.model)
+            self.model = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load(self, arch: ArchConfig, state: Dict[str, torch.Tensor], device_index: int):
+        self.close()
+        wa = WtArch()
+        wa.n_ratios = len(arch.ratios)
+        for i, r in enumerate(arch.ratios):
+            wa.ratios[i] = int(r)
+        wa.vq_bins, wa.num_quantizers, wa.input_channels = arch.vq_bins, arch.num_quantizers, arch.input_channels
+        wa.dim, wa.intermediate_dim, wa.num_layers = arch.dim, arch.intermediate_dim, arch.num_layers
+        wa.adanorm_num_embeddings = arch.adanorm_num_embeddings
+        wa.n_fft, wa.hop_length = arch.n_fft, arch.hop_length
+        wa.padding_same = 1 if arch.padding == "same" else 0
+        arrs = []
+        tens = (WtTensor * len(state))()
+        for i, (k, v) in enumerate(state.items()):
+            a = np.ascontiguousarray(v.detach().to("cpu", torch.float32).numpy())
+            arrs.append(a)
+            tens[i].name = k.encode()
+            tens[i].data = a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+            tens[i].numel = a.size
+        check(lib.wt_model_create(ctypes.byref(wa), tens, len(state), device_index, ctypes.byref(self.model)),
+              "wt_model_create")
+        self.device_index = device_index
+
+    def plan(self, kind: int, B: int, length: int, flags: int, device: torch.device):
+        key = (kind, B, length, flags)
+        hit = self.plans.get(key)
+        if hit is not None:
+            return hit
+        if len(self.plans) >= 8:                      # small LRU: drop the oldest plan + workspace
+            old = next(iter(self.plans))
+            lib.wt_plan_destroy(self.plans.pop(old)[0])
+        p = ctypes.c_void_p()
+        check(lib.wt_plan_create(self.model, kind, B, length, flags, ctypes.byref(p)), "wt_plan_create")
+        ws = torch.empty(lib.wt_plan_workspace_bytes(p), dtype=torch.uint8, device=device)
+        self.plans[key] = (p, ws)
+        return p, ws
+
+
+def _stream_ptr(device: torch.device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
+    return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+# ------------------------------------------------------------------------------ public class
+class WavTokenizer(nn.Module):
+    """Same surface as the reference class (decoder/pretrained.py:32)."""
+
+    def __init__(self, feature_extractor: EncodecFeatures, backbone: VocosBackbone, head: ISTFTHead,
+                 arch: Optional[ArchConfig] = None):
+        super().__init__()
+        self.feature_extractor = feature_extractor
+        self.backbone = backbone
+        self.head = head
+        self._arch = arch
+        self._engine = _Engine()
+        self._dirty = True
+        self._plan_flags = 0
+        for m in (feature_extractor, backbone, head):
+            m._bind(self)
+
+    # -- construction (pretrained.py:46-156) ---------------------------------------------------
+    @classmethod
+    def _from_config_node(cls, node: Dict[str, Any]) -> "WavTokenizer":
+        arch = arch_from_yaml_dict({"model": {"init_args": node}})
+        fe, bb, hd = _build_tree(arch)
+        return cls(feature_extractor=fe, backbone=bb, head=hd, arch=arch)
+
+    @classmethod
+    def from_arch(cls, arch: ArchConfig) -> "WavTokenizer":
+        fe, bb, hd = _build_tree(arch)
+        return cls(feature_extractor=fe, backbone=bb, head=hd, arch=arch)
+
+    @classmethod
+    def from_hparams(cls, config_path: str) -> "WavTokenizer":
+        with open(config_path, "r") as f:
+            config = yaml.safe_load(f)
+        return cls._from_config_node(config)
+
+    @classmethod
+    def from_hparams0802(cls, config_path: str) -> "WavTokenizer":
+        with open(config_path, "r") as f:
+            config = yaml.safe_load(f)
+        return cls._from_config_node(config["model"]["init_args"])
+
+    @staticmethod
+    def _filter_state(state_dict_raw: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        # pretrained.py:103-105: drops the discriminators of the Lightning checkpoint
+        return {k: v for k, v in state_dict_raw.items()
+                if k.startswith("backbone.") or k.startswith("head.") or k.startswith("feature_extractor.")}
+
+    @staticmethod
+    def _read_ckpt(model_path: str) -> Dict[str, torch.Tensor]:
+        # Lightning .ckpt: a pickle; only tensors are read (weights_only), nothing else is executed
+        return torch.load(model_path, map_location="cpu", weights_only=True)["state_dict"]
+
+    @classmethod
+    def from_pretrained0802(cls, config_path: str, model_path: str) -> "WavTokenizer":
+        model = cls.from_hparams0802(config_path)
+        model.load_state_dict(cls._filter_state(cls._read_ckpt(model_path)))
+        model.eval()
+        return model
+
+    @classmethod
+    def from_pretrained0911(cls, config_path: str, model_folder_path: str) -> "WavTokenizer":
+        """Average of the three `vocos_*` checkpoints with the lowest val loss in the file name
+        (pretrained.py:117-156)."""
+        model = cls.from_hparams0802(config_path)
+        models = os.listdir(model_folder_path)
+        val_loss = sorted(item[-11:-5] for item in models if item.startswith("vocos_"))[:3]
+        state_dicts = []
+        for item in models:
+            if not item.startswith("vocos_") or item[-11:-5] not in val_loss:
+                continue
+            state_dicts.append(cls._filter_state(cls._read_ckpt(model_folder_path + "/" + item)))
+        state_dict = {}
+        for kk in state_dicts[0].keys():
+            vv = state_dicts[0][kk]
+            for ss in state_dicts[1:]:
+                vv = vv + ss[kk]
+            state_dict[kk] = vv / len(state_dicts)
+        model.load_state_dict(state_dict)
+        model.eval()
+        return model
+
+    @classmethod
+    def from_pretrained(cls, repo_id: str) -> "WavTokenizer":
+        from huggingface_hub import hf_hub_download
+        config_path = hf_hub_download(repo_id=repo_id, filename="config.yaml")
+        model_path = hf_hub_download(repo_id=repo_id, filename="pytorch_model.bin")
+        model = cls.from_hparams(config_path)
+        state_dict = torch.load(model_path, map_location="cpu", weights_only=True)
+        model.load_state_dict(state_dict, strict=False)
+        model.eval()
+        return model
+
+    # -- nn.Module protocol: any weight or device change invalidates the packed HBM copy -------
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._dirty = True
+        return out
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        self._dirty = True
+        return out
+
+    def refresh_weights(self):
+        """Call after mutating parameters in place."""
+        self._dirty = True
+
+    def set_debug_keep_stages(self, on: bool):
+        """Parity tests: keep every stage buffer of the next plans distinct in the workspace."""
+        self._plan_flags = _capi.WT_PLAN_FLAG_KEEP_STAGES if on else 0
+
+    @property
+    def arch(self) -> ArchConfig:
+        return self._arch
+
+    @property
+    def hop_length(self) -> int:
+        return self._arch.hop
+
+    def _device(self) -> torch.device:
+        return self.backbone.embed.weight.device
+
+    def _ensure_engine(self) -> torch.device:
+        dev = self._device()
+        if dev.type != "cuda":
+            raise RuntimeError("wavtokenizer_amd runs only on an AMD GPU: move the model with .to('cuda'). "
+                               "There is no CPU path in this package.")
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        if self._dirty or self._engine.device_index != idx:
+            self._engine.load(self._arch, self.state_dict(), idx)
+            self._dirty = False
+        return torch.device("cuda", idx)
+
+    @staticmethod
+    def _as_input(x: torch.Tensor, dev: torch.device, dtype=torch.float32) -> torch.Tensor:
+        if x.device != dev:
+            raise RuntimeError(f"input is on {x.device} but the model is on {dev}")
+        return x.to(dtype).contiguous()
+
+    # -- kernels ------------------------------------------------------------------------------------
+    def _run_encode(self, audio: torch.Tensor, want_emb: bool = True):
+        dev = self._ensure_engine()
+        assert audio.dim() == 2, "expected audio of shape (B, T)"
+        audio = self._as_input(audio, dev)
+        B, T = audio.shape
+        plan, ws = self._engine.plan(_capi.WT_PLAN_ENCODE, B, T, self._plan_flags, dev)
+        L = int(lib.wt_plan_frames(plan))
+        feats = torch.empty((B, 512, L), dtype=torch.float32, device=dev)
+        codes = torch.empty((1, B, L), dtype=torch.int64, device=dev)
+        emb = torch.empty((B, 512, L), dtype=torch.float32, device=dev) if want_emb else None
+        check(lib.wt_encode(plan, _ptr(audio), _ptr(feats), _ptr(codes), _ptr(emb), _ptr(ws), _stream_ptr(dev)),
+              "wt_encode")
+        return feats, codes, emb
+
+    def _bandwidth_index(self, bandwidth_id) -> int:
+        if bandwidth_id is None:
+            raise AssertionError("bandwidth_id is required (decoder/models.py:227)")
+        if isinstance(bandwidth_id, torch.Tensor):
+            if bandwidth_id.numel() != 1:
+                raise ValueError("bandwidth_id must hold one index (the reference broadcasts a (1, dim) embedding row)")
+            return int(bandwidth_id.reshape(-1)[0])
+        return int(bandwidth_id)
+
+    def _run_decode(self, features: torch.Tensor, bandwidth_id, want_backbone: bool = False):
+        dev = self._ensure_engine()
+        assert features.dim() == 3 and features.shape[1] == self._arch.input_channels, "expected features (B, 512, L)"
+        bw = self._bandwidth_index(bandwidth_id)
+        features = self._as_input(features, dev)
+        B, _, L = features.shape
+        plan, ws = self._engine.plan(_capi.WT_PLAN_DECODE, B, L, self._plan_flags, dev)
+        wav = torch.empty((B, L * self._arch.hop_length), dtype=torch.float32, device=dev)
+        bb = torch.empty((B, L, self._arch.dim), dtype=torch.float32, device=dev) if want_backbone else None
+        check(lib.wt_decode(plan, _ptr(features), bw, _ptr(wav), _ptr(bb), _ptr(ws), _stream_ptr(dev)), "wt_decode")
+        return wav, bb
+
+    def _run_seanet_decoder(self, z: torch.Tensor) -> torch.Tensor:
+        dev = self._ensure_engine()
+        z = self._as_input(z, dev)
+        B, _, L = z.shape
+        plan, ws = self._engine.plan(_capi.WT_PLAN_SEANET_DECODER, B, L, self._plan_flags, dev)
+        out = torch.empty((B, 1, L * self._arch.hop), dtype=torch.float32, device=dev)
+        check(lib.wt_seanet_decode(plan, _ptr(z), _ptr(out), _ptr(ws), _stream_ptr(dev)), "wt_seanet_decode")
+        return out
+
+    def debug_stage(self, kind: int, B: int, length: int, name: str) -> torch.Tensor:
+        """Flat fp32 view of a named stage buffer of the cached plan (after a KEEP_STAGES run)."""
+        plan, ws = self._engine.plans[(kind, B, length, self._plan_flags)]
+        off, n = ctypes.c_size_t(), ctypes.c_size_t()
+        check(lib.wt_plan_find_buffer(plan, name.encode(), ctypes.byref(off), ctypes.byref(n)), "wt_plan_find_buffer")
+        return ws[off.value: off.value + 4 * n.value].view(torch.float32)
+
+    # -- reference API (pretrained.py:159-239) --------------------------------------------------------
+    @torch.inference_mode()
+    def forward(self, audio_input: torch.Tensor, **kwargs: Any) -> torch.Tensor:
+        features, _, _ = self.feature_extractor(audio_input, **kwargs)
+        return self.decode(features, **kwargs)
+
+    @torch.inference_mode()
+    def encode(self, audio_input: torch.Tensor, **kwargs: Any):
+        features, discrete_codes, _ = self.feature_extractor(audio_input, **kwargs)
+        return features, discrete_codes
+
+    @torch.inference_mode()
+    def encode_infer(self, audio_input: torch.Tensor, **kwargs: Any):
+        features, discrete_codes, _ = self.feature_extractor.infer(audio_input, **kwargs)
+        return features, discrete_codes
+
+    @torch.inference_mode()
+    def decode(self, features_input: torch.Tensor, **kwargs: Any) -> torch.Tensor:
+        return self._run_decode(features_input, kwargs.get("bandwidth_id"))[0]
+
+    @torch.inference_mode()
+    def codes_to_features(self, codes: torch.Tensor) -> torch.Tensor:
+        assert isinstance(self.feature_extractor, EncodecFeatures), \
+            "Feature extractor should be an instance of EncodecFeatures"
+        dev = self._ensure_engine()
+        if codes.dim() == 2:
+            codes = codes.unsqueeze(1)
+        codes = self._as_input(codes, dev, torch.int64)
+        K, B, L = codes.shape
+        feats = torch.empty((B, 512, L), dtype=torch.float32, device=dev)
+        check(lib.wt_codes_to_features(self._engine.model, _ptr(codes), K, B, L, _ptr(feats), _stream_ptr(dev)),
+              "wt_codes_to_features")
+        return feats
