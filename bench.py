@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py — audio-seconds/sec of WavTokenizer encode_infer + decode on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--arch hop600|hop320] [--clips 64]
+
+One "step" = one encode_infer + decode round trip of `--clips` independent 3 s / 24 kHz clips
+per GPU (BASELINE.json configs[1]: WavTokenizer-small-600, batch 64 x 3 s), inputs already
+resident in HBM, synthetic clips and random-init weights of the real architecture
+(wavtokenizer_amd/synth.py).  For N > 1 the driver launches one rank per GPU with
+torch.distributed.run; clips shard across ranks with no collective on the data path (weak
+scaling) and the per-step codes all-gather + waveform gather to rank 0 over RCCL is inside the
+timed region.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline     — dominant kernel (ConvNeXt pwconv1 fp32-MFMA GEMM, 12 launches per step): achieved
+                 = 2*M*N*K per launch / mean launch duration, from HIP events recorded on the
+                 launch stream during the timed steps (wt_plan_set_timing).
+  cpu_baseline — the oracle (oracle/cpu_ref.py, same ATen op sequence as the reference) timed on
+                 this host's cores, rank 0 at N=1 only, on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+HBM_PEAK_GBS = 8000.0
+CLIP_SECONDS = 3
+SAMPLE_RATE = 24000
+# algorithmic GFLOP per 3 s clip (2*MAC: convs, linears, LSTM, VQ, attention)
+GFLOP_PER_CLIP = {"hop600": 20.852, "hop320": 38.910}
+WORKLOAD = {"hop600": "WavTokenizer-small-600-24k-4096 (40 tok/s), encode_infer+decode round trip, 3 s 24 kHz clips",
+            "hop320": "WavTokenizer-small-320-24k-4096 (75 tok/s), encode_infer+decode round trip, 3 s 24 kHz clips"}
+
+
+def cpu_baseline(arch_name, sd, clips_np):
+    """Oracle on the host cores: B=1 (BASELINE configs[0]) and a B=16 batch; returns the faster."""
+    from oracle.cpu_ref import OracleWavTokenizer
+    from wavtokenizer_amd import NAMED_ARCHS
+    orc = OracleWavTokenizer(NAMED_ARCHS[arch_name], sd)
+    bw = torch.tensor([0])
+    cores = torch.get_num_threads()
+    results = {}
+    budget = time.time() + 40.0
+    for B, reps in ((1, 8), (16, 3)):
+        x = torch.from_numpy(clips_np[:B])
+        with torch.inference_mode():
+            f, _ = orc.encode_infer(x, bw)      # warm-up
+            orc.decode(f, bw)
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                f, _ = orc.encode_infer(x, bw)
+                orc.decode(f, bw)
+                ts.append(time.perf_counter() - t0)
+                if time.time() > budget:
+                    break
+        ts.sort()
+        results[B] = B * CLIP_SECONDS / ts[len(ts) // 2]
+    best_b = max(results, key=results.get)
+    return {"value": round(results[best_b], 2), "unit": "audio-s/s", "cores": cores, "kind": "port",
+            "sample": "oracle/cpu_ref.py (reference ATen op sequence, fp32) on %d torch threads; median round trip of "
+                      "B=1 x3s (8 reps): %.1f audio-s/s, B=16 x3s (3 reps): %.1f audio-s/s; value = the faster"
+                      % (cores, results[1], results[16])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--arch", default="hop600", choices=["hop600", "hop320"])
+    ap.add_argument("--clips", type=int, default=64, help="clips per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from wavtokenizer_amd import WavTokenizer, NAMED_ARCHS, synth, _capi
+    arch = NAMED_ARCHS[args.arch]
+    sd = synth.make_state_dict(arch, seed=0)
+    model = WavTokenizer.from_arch(arch)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    model = model.eval().to(dev)
+    B, T = args.clips, CLIP_SECONDS * SAMPLE_RATE
+    clips_np = synth.make_clips(B, T, seed=1000 * 2 + rank)       # seed = 1000*config + index
+    wav = torch.from_numpy(clips_np).to(dev)
+    bw = torch.tensor([0])
+    L = arch.frames(T)
+
+    codes_all = torch.empty((world, 1, B, L), dtype=torch.int64, device=dev) if world > 1 else None
+    wav_all = [torch.empty((B, L * arch.hop_length), device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step():
+        feats, codes = model.encode_infer(wav, bandwidth_id=bw)
+        out = model.decode(feats, bandwidth_id=bw)
+        if world > 1 and not args.no_gather:
+            dist.all_gather_into_tensor(codes_all, codes)            # 8*L bytes per clip
+            dist.gather(out, wav_all, dst=0)                         # waveforms to rank 0
+        return codes, out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    # time the dominant kernel with HIP events on its launch stream during the timed steps
+    dplan = model._engine.plans[(_capi.WT_PLAN_DECODE, B, L, 0)][0]
+    _capi.check(_capi.lib.wt_plan_set_timing(dplan, b"cnx.pwconv1"), "wt_plan_set_timing")
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tot_ms, n_l = ctypes.c_double(), ctypes.c_int64()
+    _capi.check(_capi.lib.wt_plan_read_timing(dplan, ctypes.byref(tot_ms), ctypes.byref(n_l), 1), "wt_plan_read_timing")
+    _capi.lib.wt_plan_set_timing(dplan, b"")
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * B * CLIP_SECONDS * args.steps / elapsed
+        Mrows = B * L
+        flops = 2.0 * Mrows * arch.intermediate_dim * arch.dim
+        kern_ms = tot_ms.value / max(1, n_l.value)
+        achieved = flops / (kern_ms * 1e-3) / 1e12
+        e2e_tflops = GFLOP_PER_CLIP[args.arch] * B * 1e9 / (ms_per_step * 1e-3) / 1e12
+        line = {
+            "metric": "audio-seconds/sec encode+decode, 24 kHz 3 s clips",
+            "value": round(value, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": WORKLOAD[args.arch], "arch": args.arch, "clips_per_gpu": B,
+                       "global_clips": world * B, "clip_seconds": CLIP_SECONDS, "frames_per_clip": L,
+                       "weights": "random-init (synth seed 0)", "parallelism": f"clips sharded dp{world}",
+                       "gather": "codes all_gather + waveform gather to rank 0 (RCCL) inside the step" if world > 1 and not args.no_gather else "none"},
+            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<128,128,2,2,PRO_NONE,EPI_BIAS_GELU> (ConvNeXt pwconv1)",
+                         "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "flops_per_launch": flops, "avg_launch_ms": round(kern_ms, 4), "launches_timed": n_l.value,
+                         "end_to_end_tflops": round(e2e_tflops, 2),
+                         "end_to_end_frac": round(e2e_tflops / PEAK_FP32_MFMA_TFLOPS, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.arch, sd, clips_np)
+            line["speedup_vs_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -94,6 +94,15 @@ int    wt_plan_num_launches(const wt_plan* p);
 int    wt_plan_find_buffer(const wt_plan* p, const char* name, size_t* offset, size_t* numel);
 int    wt_plan_buffer_name(const wt_plan* p, int32_t index, const char** name);
 
+/* Measurement hook (bench.py's roofline leg; no counterpart in the reference): HIP events are
+ * recorded on the call's stream around every step whose name contains `name_substr` ("" / NULL
+ * turns it off).  wt_plan_read_timing waits for the recorded events and returns the summed
+ * milliseconds and the number of timed launches since the last reset.  Not thread-safe. */
+int wt_plan_num_steps(const wt_plan* p);
+int wt_plan_step_name(const wt_plan* p, int32_t index, const char** name);
+int wt_plan_set_timing(const wt_plan* p, const char* name_substr);
+int wt_plan_read_timing(const wt_plan* p, double* total_ms, int64_t* launches, int32_t reset);
+
 /* Replaces: WavTokenizer.encode_infer (decoder/pretrained.py:186-189) ->
  * EncodecFeatures.infer (decoder/feature_extractors.py:131-142): SEANetEncoder
  * (encoder/modules/seanet.py:143) + ResidualVectorQuantizer.infer (encoder/quantization/vq.py:115-140).

@@ -16,7 +16,8 @@ LIB_PATH = os.path.join(_HERE, "libwavtok_hip.so")
 EXPORTS = [
     "wt_last_error", "wt_version", "wt_model_create", "wt_model_destroy", "wt_model_hop", "wt_model_weight_bytes",
     "wt_plan_create", "wt_plan_destroy", "wt_plan_workspace_bytes", "wt_plan_frames", "wt_plan_num_launches",
-    "wt_plan_find_buffer", "wt_plan_buffer_name", "wt_encode", "wt_codes_to_features", "wt_decode",
+    "wt_plan_find_buffer", "wt_plan_buffer_name", "wt_plan_num_steps", "wt_plan_step_name", "wt_plan_set_timing",
+    "wt_plan_read_timing", "wt_encode", "wt_codes_to_features", "wt_decode",
     "wt_seanet_decode", "wt_sconv1d", "wt_vq_workspace_bytes", "wt_vq_nearest",
 ]
 
@@ -63,6 +64,10 @@ def _load() -> ctypes.CDLL:
     lib.wt_plan_num_launches.argtypes = [c_void_p]
     lib.wt_plan_find_buffer.argtypes = [c_void_p, c_char_p, POINTER(c_size_t), POINTER(c_size_t)]
     lib.wt_plan_buffer_name.argtypes = [c_void_p, c_int32, POINTER(c_char_p)]
+    lib.wt_plan_num_steps.argtypes = [c_void_p]
+    lib.wt_plan_step_name.argtypes = [c_void_p, c_int32, POINTER(c_char_p)]
+    lib.wt_plan_set_timing.argtypes = [c_void_p, c_char_p]
+    lib.wt_plan_read_timing.argtypes = [c_void_p, POINTER(ctypes.c_double), POINTER(c_int64), c_int32]
     lib.wt_encode.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.wt_codes_to_features.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p, c_void_p]
     lib.wt_decode.argtypes = [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]

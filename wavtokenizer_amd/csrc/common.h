@@ -91,6 +91,8 @@ int launch_conv_last(const float* x /*[B][T][Cin]*/, const float* w /*[k][Cin]*/
 int launch_transpose(const float* in, float* out, int B, int R, int C, hipStream_t s);  // [B][R][C] -> [B][C][R]
 int launch_gn_stats(const float* x, const float* gamma, const float* beta, float* scale, float* shift, int B, int L,
                     int C, int groups, float eps, hipStream_t s);
+int launch_gn_apply(const float* x, const float* gamma, const float* beta, float* scale, float* shift, float* y,
+                    int swish, int B, int L, int C, int groups, float eps, hipStream_t s);
 int launch_affine(const float* x, const float* scale, const float* shift, float* y, int B, int L, int C, hipStream_t s);
 enum RowNormMode : int { RN_DWCONV = 0, RN_PLAIN = 1, RN_AFFINE_IN = 2 };
 int launch_rownorm(int mode, const float* x, float* y, int B, int L, int C, const float* dw_w /*[7][C]*/,

@@ -13,6 +13,8 @@
 // * register-prefetched double buffering, one barrier per 32-deep K step;
 // * workgroup id -> tile remap keeps tiles that share A rows on one XCD's L2.
 #include "common.h"
+#include <stdlib.h>
+#include <cmath>
 
 namespace wt {
 
@@ -59,79 +61,102 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     const float* __restrict__ Ag = p.A + (long)z * p.zA;
     const float* __restrict__ Wg = p.W + (long)z * p.zW;
 
+    // ---- operands are read through buffer resources: an out-of-range offset returns 0, so padding,
+    //      ragged tile edges and K tails need no branches (cdna guide T8)
+    const int nclips = p.M / p.T_out;
+    const int m_first = bm * BM < p.M ? bm * BM : p.M - 1;
+    const int clip0 = m_first / p.T_out;
+    const float* Ablk = Ag + (long)clip0 * p.a_bstride;
+    const long a_span = ((long)(nclips - clip0 - 1) * p.a_bstride + (long)p.T_in * p.a_rstride) * 4;
+    const long w_span = (long)p.N * p.w_rstride * 4;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(Ablk), 0, (int)(a_span < 0x7fffffffL ? a_span : 0x7fffffffL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(Wg), 0, (int)(w_span < 0x7fffffffL ? w_span : 0x7fffffffL), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;     // stays out of range after the (< 2^30) K advance
+
+    // ---- per-(tap, tile row) byte offsets of the gathered A rows, resolved once into LDS:
+    //      reflect / zero padding and ragged tile edges become the OOB marker, the K loop is branch-free
+    unsigned* s_rowoff = reinterpret_cast<unsigned*>(smem + 2 * (BM + BN) * LDS_PITCH);   // [taps][BM]
+    for (int e = tid; e < p.taps * BM; e += 256) {
+        const int tp = e / BM, r = e - tp * BM;
+        const int m = bm * BM + r;
+        unsigned off = OOB;
+        if (m < p.M) {
+            const int b = m / p.T_out;
+            const int t = m - b * p.T_out;
+            int pos = t * p.stride - p.pad_left + tp * p.dil;
+            bool ok;
+            if (p.pad_mode == PAD_REFLECT) {
+                pos = pos < 0 ? -pos : pos;
+                pos = pos >= p.Tp ? 2 * (p.Tp - 1) - pos : pos;
+                ok = pos < p.T_in;
+            } else {
+                ok = (pos >= 0) && (pos < p.T_in);
+            }
+            if (ok) off = (unsigned)(((long)(b - clip0) * p.a_bstride + (long)pos * p.a_rstride) * 4);
+        }
+        s_rowoff[e] = off;
+    }
+
     // ---- per-thread staging rows (fixed across the K loop)
     const int srow = tid >> 3;        // 0..31
     const int kq4 = (tid & 7) * 4;    // k offset of this thread's float4 inside a K step
-    const float* a_base[NA];
-    int a_pos0[NA];
-    int a_clip[NA];
-    bool a_ok[NA];
+    int a_clipc[NA];                  // clip * Cin (affine prologue table row)
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        int m = bm * BM + srow + 32 * i;
-        a_ok[i] = m < p.M;
-        int mm = a_ok[i] ? m : 0;
-        int b = mm / p.T_out;
-        int t = mm - b * p.T_out;
-        a_clip[i] = b;
-        a_base[i] = Ag + (long)b * p.a_bstride;
-        a_pos0[i] = t * p.stride - p.pad_left;
+        const int m = bm * BM + srow + 32 * i;
+        a_clipc[i] = ((m < p.M ? m : 0) / p.T_out) * p.Cin;
     }
-    const float* w_base[NB];
-    bool w_ok[NB];
+    unsigned w_off[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        int n = bn * BN + srow + 32 * i;
-        w_ok[i] = n < p.N;
-        w_base[i] = Wg + (long)(w_ok[i] ? n : 0) * p.w_rstride;
+        const int n = bn * BN + srow + 32 * i;
+        w_off[i] = n < p.N ? (unsigned)((long)n * p.w_rstride * 4) + (unsigned)kq4 * 4u : OOB;
     }
+    __syncthreads();
 
     f32x4 ra[NA], rb[NB];
+    int ld_idx[NA];                   // affine prologue: index of (clip, channel), or -1 for padding
 
     auto load_tile = [&](int k0, int tap, int ci0) {
-        const int kk = k0 + kq4;
-        const bool kin = kk < p.K;
-        const int ci = ci0 + kq4;
+        // K tail (only K = 16 has one): the OR keeps the offset >= 2^31 whatever is added
+        const unsigned kmask = (k0 + kq4 < p.K) ? 0u : OOB;
+        const unsigned kadv = (unsigned)(ci0 + kq4) * 4u;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            int pos = a_pos0[i] + tap * p.dil;
-            bool ok = a_ok[i] && kin;
-            if (p.pad_mode == PAD_REFLECT) {
-                if (pos < 0) pos = -pos;
-                if (pos >= p.Tp) pos = 2 * (p.Tp - 1) - pos;
-                ok = ok && (pos < p.T_in);
-            } else {
-                ok = ok && (pos >= 0) && (pos < p.T_in);
-            }
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) {
-                v = *reinterpret_cast<const f32x4*>(a_base[i] + (long)pos * p.a_rstride + ci);
-                if (PRO == PRO_ELU) {
-                    v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w);
-                } else if (PRO == PRO_AFFINE || PRO == PRO_AFFINE_SWISH) {
-                    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.pro_scale + (long)a_clip[i] * p.Cin + ci);
-                    const f32x4 sh = *reinterpret_cast<const f32x4*>(p.pro_shift + (long)a_clip[i] * p.Cin + ci);
-                    v = v * sc + sh;
-                    if (PRO == PRO_AFFINE_SWISH) {
-                        v.x = swish(v.x); v.y = swish(v.y); v.z = swish(v.z); v.w = swish(v.w);
-                    }
-                }
-            }
-            ra[i] = v;
+            const unsigned ro = s_rowoff[tap * BM + srow + 32 * i];
+            const unsigned off = (ro | kmask) + kadv;
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, 0, 0));
+            if (PRO == PRO_AFFINE || PRO == PRO_AFFINE_SWISH)
+                ld_idx[i] = (a_clipc[i] + ci0 + kq4) | (int)((ro | kmask) & OOB ? -1 : 0);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (w_ok[i] && kin) v = *reinterpret_cast<const f32x4*>(w_base[i] + kk);
-            rb[i] = v;
+            const unsigned off = (w_off[i] | kmask) + (unsigned)k0 * 4u;
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)off, 0, 0));
         }
     };
     auto store_tile = [&](int buf) {
         float* as = As + buf * BM * LDS_PITCH;
         float* bs = Bs + buf * BN * LDS_PITCH;
 #pragma unroll
-        for (int i = 0; i < NA; ++i)
-            *reinterpret_cast<f32x4*>(as + (srow + 32 * i) * LDS_PITCH + kq4) = ra[i];
+        for (int i = 0; i < NA; ++i) {
+            f32x4 v = ra[i];
+            if (PRO == PRO_ELU) {                                  // elu(0) = 0: padding stays 0
+                v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w);
+            } else if (PRO == PRO_AFFINE || PRO == PRO_AFFINE_SWISH) {
+                const int idx = ld_idx[i] < 0 ? 0 : ld_idx[i];
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(p.pro_scale + idx);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(p.pro_shift + idx);
+                v = v * sc + sh;
+                if (PRO == PRO_AFFINE_SWISH) {
+                    v.x = swish(v.x); v.y = swish(v.y); v.z = swish(v.z); v.w = swish(v.w);
+                }
+                if (ld_idx[i] < 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};   // padding is zero AFTER the norm
+            }
+            *reinterpret_cast<f32x4*>(as + (srow + 32 * i) * LDS_PITCH + kq4) = v;
+        }
 #pragma unroll
         for (int i = 0; i < NB; ++i)
             *reinterpret_cast<f32x4*>(bs + (srow + 32 * i) * LDS_PITCH + kq4) = rb[i];
@@ -148,7 +173,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     const int nk = (p.K + BK - 1) / BK;
     // (tap, ci0) of the K step being loaded; host guarantees taps == 1 or Cin % 32 == 0
     int tap = 0, ci0 = 0;
-    load_tile(0, tap, ci0);
+    load_tile(0, 0, 0);
     store_tile(0);
     __syncthreads();
 
@@ -157,7 +182,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         const int buf = kt & 1;
         if (kt + 1 < nk) {
             ci0 += BK;
-            if (p.taps > 1 && ci0 >= p.Cin) { ci0 -= p.Cin; ++tap; }
+            if (p.taps > 1 && ci0 >= p.Cin) { ci0 = 0; ++tap; }
             load_tile((kt + 1) * BK, tap, ci0);
         }
         const float* as = As + buf * BM * LDS_PITCH + (wm * WM) * LDS_PITCH + frag_off;
@@ -299,11 +324,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 template <int BM, int BN, int WMs, int WNs, int PRO, int EPI>
 static int launch_one(const GemmArgs& a, hipStream_t s) {
     static bool attr_set = false;
-    constexpr size_t smem = 2ull * (BM + BN) * LDS_PITCH * sizeof(float);
+    const size_t smem = 2ull * (BM + BN) * LDS_PITCH * sizeof(float) + (size_t)a.taps * BM * sizeof(unsigned);
+    constexpr size_t smem_max = 2ull * (BM + BN) * LDS_PITCH * sizeof(float) + 32ull * BM * sizeof(unsigned);
     auto kern = gemm_kernel<BM, BN, WMs, WNs, PRO, EPI>;
     if (!attr_set) {
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max));
         attr_set = true;
     }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
@@ -313,13 +339,39 @@ static int launch_one(const GemmArgs& a, hipStream_t s) {
     return 0;
 }
 
+// experiment hook (tools/gemm_bench.py): WT_GEMM_TILE picks another tile for plain bias GEMMs
+static int tile_override() {
+    static int v = -2;
+    if (v == -2) { const char* e = getenv("WT_GEMM_TILE"); v = e ? atoi(e) : -1; }
+    return v;
+}
+
 template <int PRO, int EPI>
 static int launch_tiled(const GemmArgs& a, hipStream_t s) {
+    if constexpr (PRO == PRO_NONE && EPI == EPI_BIAS) {
+        switch (tile_override()) {
+            case 1: return launch_one<128, 64, 2, 2, PRO, EPI>(a, s);
+            case 2: return launch_one<128, 96, 4, 1, PRO, EPI>(a, s);
+            case 3: return launch_one<128, 64, 4, 1, PRO, EPI>(a, s);
+            case 4: return launch_one<64, 128, 1, 4, PRO, EPI>(a, s);
+            case 5: return launch_one<128, 192, 2, 2, PRO, EPI>(a, s);
+            default: break;
+        }
+    }
     if constexpr (EPI == EPI_HEAD || EPI == EPI_ARGMAX) {
         return launch_one<128, 128, 2, 2, PRO, EPI>(a, s);
     } else {
         if (a.N <= 32) return launch_one<128, 32, 4, 1, PRO, EPI>(a, s);
         if (a.N <= 64) return launch_one<128, 64, 2, 2, PRO, EPI>(a, s);
+        if (a.N % 96 == 0) {
+            // 512 workgroup slots (2 per CU): take 128x96 tiles when the last round of 128x128
+            // tiles would leave most of the chip idle (e.g. 7680x768: 360 tiles on 512 slots)
+            const long tm = (a.M + 127) / 128;
+            const long t128 = tm * ((a.N + 127) / 128) * a.nz, t96 = tm * (a.N / 96) * a.nz;
+            const double r128 = (double)t128 / 512.0, r96 = (double)t96 / 512.0;
+            const double eff128 = r128 / std::ceil(r128), eff96 = 0.97 * r96 / std::ceil(r96);
+            if (eff96 > eff128) return launch_one<128, 96, 4, 1, PRO, EPI>(a, s);
+        }
         return launch_one<128, 128, 2, 2, PRO, EPI>(a, s);
     }
 }
@@ -332,6 +384,14 @@ static int check_args(const GemmArgs& a) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) { set_error("gemm: empty problem"); return -1; }
     if (a.K % 4 != 0 || a.Cin % 4 != 0) { set_error("gemm: K and Cin must be multiples of 4"); return -1; }
     if (a.taps > 1 && a.Cin % BK != 0) { set_error("gemm: multi-tap gather needs Cin % 32 == 0"); return -1; }
+    if (a.taps > 32) { set_error("gemm: at most 32 taps"); return -1; }
+    {   // 31-bit byte offsets inside one workgroup's window of A and inside W
+        const long clips_per_tile = 128 / a.T_out + 2;
+        if ((clips_per_tile * a.a_bstride + (long)a.T_in * a.a_rstride) * 4 >= 0x40000000L ||
+            (long)a.N * a.w_rstride * 4 >= 0x40000000L) {
+            set_error("gemm: operand window exceeds the 1 GiB buffer-offset range"); return -1;
+        }
+    }
     if (a.K != a.taps * a.Cin) { set_error("gemm: K != taps*Cin"); return -1; }
     if (a.T_out <= 0 || a.M % a.T_out != 0) { set_error("gemm: M must be nclips*T_out"); return -1; }
     if ((a.a_rstride % 4) || (a.a_bstride % 4) || (a.w_rstride % 4) || (a.zA % 4) || (a.zW % 4)) {

@@ -436,8 +436,15 @@ struct wt_plan {
     int64_t len = 0, L = 0, T = 0;
     std::vector<wt::BufSpec> bufs;
     std::vector<std::function<int(const wt::RunCtx&)>> steps;
+    std::vector<std::string> step_names;
     size_t ws_bytes = 0;
     int n_launches = 0;
+    // optional HIP-event timing of the steps whose name contains `timing_filter` (bench.py roofline
+    // leg); mutable profiling state, not thread-safe, off by default
+    mutable std::string timing_filter;
+    mutable std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending, ev_free;
+    mutable double timing_ms = 0.0;
+    mutable long timing_n = 0;
 
     int buf(const std::string& name, size_t numel) {
         wt::BufSpec b;
@@ -445,14 +452,18 @@ struct wt_plan {
         bufs.push_back(b);
         return (int)bufs.size() - 1;
     }
-    void step(std::initializer_list<int> used, std::function<int(const wt::RunCtx&)> fn, int launches = 1) {
+    void step(std::initializer_list<int> used, std::function<int(const wt::RunCtx&)> fn, int launches = 1,
+              const std::string& name = "") {
         const int s = (int)steps.size();
+        std::string nm = name;
         for (int id : used) {
             if (id < 0) continue;
             bufs[id].first = std::min(bufs[id].first, s);
             bufs[id].last = std::max(bufs[id].last, s);
+            if (name.empty()) nm = bufs[id].name;      // default: the last buffer the step touches
         }
         steps.push_back(std::move(fn));
+        step_names.push_back(nm);
         n_launches += launches;
     }
     float* ptr(const wt::RunCtx& c, int id) const { return reinterpret_cast<float*>(c.ws + bufs[id].off); }
@@ -631,7 +642,7 @@ static int build_encode(wt_plan* P) {
         a.vq_xx = P->ptr(c, xx); a.vq_ee = M->ee; a.vq_pval = P->ptr(c, pv);
         a.vq_pidx = reinterpret_cast<int*>(P->ptr(c, pi)); a.vq_nparts = np;
         return launch_gemm(a, PRO_NONE, EPI_ARGMAX, c.stream);
-    });
+    }, 1, "vq.argmin");
     P->step({pv, pi, emb}, [=](const RunCtx& c) {
         if (int rc = launch_vq_finalize(P->ptr(c, pv), reinterpret_cast<int*>(P->ptr(c, pi)), np, M->embed, c.codes,
                                         c.out_f, B, L, 512, c.stream)) return rc;
@@ -667,25 +678,28 @@ static int build_decode(wt_plan* P) {
     snapshot("bb.embed");
     const int sc = P->buf("bb.gn_scale", (size_t)B * D), sh = P->buf("bb.gn_shift", (size_t)B * D);
     const int h1 = P->buf("bb.h1", (size_t)Mrows * D);
+    const int h2 = P->buf("bb.h2", (size_t)Mrows * D);
 
-    auto resnet = [&](const PosRes& r, const std::string& name) {      // models.py:58-78
-        P->step({x, sc, sh}, [=](const RunCtx& c) {
-            return launch_gn_stats(P->ptr(c, x), r.n1w, r.n1b, P->ptr(c, sc), P->ptr(c, sh), B, L, D, 32, 1e-6f, c.stream);
-        });
-        GemmArgs a1 = zconv_args(r.c1, B, L);
+    // ResnetBlock (models.py:58-78).  GroupNorm+swish is applied ONCE per element by the statistics
+    // kernel (a second pass over its own L x 24 slab) instead of in the conv's operand staging,
+    // where every element would be re-normalised by each of the 18 (tap, column-tile) re-reads.
+    auto resnet = [&](const PosRes& r, const std::string& name) {
         P->step({x, sc, sh, h1}, [=](const RunCtx& c) {
-            GemmArgs a = a1; a.A = P->ptr(c, x); a.C = P->ptr(c, h1); a.pro_scale = P->ptr(c, sc); a.pro_shift = P->ptr(c, sh);
-            return launch_gemm(a, PRO_AFFINE_SWISH, EPI_BIAS, c.stream);
-        });
-        P->step({h1, sc, sh}, [=](const RunCtx& c) {
-            return launch_gn_stats(P->ptr(c, h1), r.n2w, r.n2b, P->ptr(c, sc), P->ptr(c, sh), B, L, D, 32, 1e-6f, c.stream);
-        });
+            return launch_gn_apply(P->ptr(c, x), r.n1w, r.n1b, P->ptr(c, sc), P->ptr(c, sh), P->ptr(c, h1), 1, B, L, D, 32, 1e-6f, c.stream);
+        }, 1, "res.gn1");
+        GemmArgs a1 = zconv_args(r.c1, B, L);
+        P->step({h1, h2}, [=](const RunCtx& c) {
+            GemmArgs a = a1; a.A = P->ptr(c, h1); a.C = P->ptr(c, h2);
+            return launch_gemm(a, PRO_NONE, EPI_BIAS, c.stream);
+        }, 1, "res.conv1");
+        P->step({h2, sc, sh, h1}, [=](const RunCtx& c) {
+            return launch_gn_apply(P->ptr(c, h2), r.n2w, r.n2b, P->ptr(c, sc), P->ptr(c, sh), P->ptr(c, h1), 1, B, L, D, 32, 1e-6f, c.stream);
+        }, 1, "res.gn2");
         GemmArgs a2 = zconv_args(r.c2, B, L);
-        P->step({h1, sc, sh, x}, [=](const RunCtx& c) {
+        P->step({h1, x}, [=](const RunCtx& c) {
             GemmArgs a = a2; a.A = P->ptr(c, h1); a.C = P->ptr(c, x); a.R = P->ptr(c, x); a.r_rstride = D;
-            a.pro_scale = P->ptr(c, sc); a.pro_shift = P->ptr(c, sh);
-            return launch_gemm(a, PRO_AFFINE_SWISH, EPI_BIAS_RES, c.stream);
-        });
+            return launch_gemm(a, PRO_NONE, EPI_BIAS_RES, c.stream);
+        }, 1, "res.conv2");
         snapshot(name);
     };
     resnet(M->res[0], "bb.pos_net.0");
@@ -695,12 +709,9 @@ static int build_decode(wt_plan* P) {
         const int vt = P->buf("bb.attn.vt", (size_t)B * D * Lp);
         const int S = P->buf("bb.attn.s", (size_t)Mrows * Lp);
         const int o = P->buf("bb.attn.o", (size_t)Mrows * D);
-        P->step({x, sc, sh}, [=](const RunCtx& c) {
-            return launch_gn_stats(P->ptr(c, x), M->at_nw, M->at_nb, P->ptr(c, sc), P->ptr(c, sh), B, L, D, 32, 1e-6f, c.stream);
-        });
         P->step({x, sc, sh, h1}, [=](const RunCtx& c) {
-            return launch_affine(P->ptr(c, x), P->ptr(c, sc), P->ptr(c, sh), P->ptr(c, h1), B, L, D, c.stream);
-        });
+            return launch_gn_apply(P->ptr(c, x), M->at_nw, M->at_nb, P->ptr(c, sc), P->ptr(c, sh), P->ptr(c, h1), 0, B, L, D, 32, 1e-6f, c.stream);
+        }, 1, "attn.gn");
         GemmArgs aqk = linear_args(M->at_Wqk, M->at_bqk, Mrows, 2 * D, D);
         P->step({h1, qk}, [=](const RunCtx& c) {
             GemmArgs a = aqk; a.A = P->ptr(c, h1); a.C = P->ptr(c, qk);
@@ -766,12 +777,12 @@ static int build_decode(wt_plan* P) {
         P->step({nrm, mid}, [=](const RunCtx& c) {
             GemmArgs a = a1; a.A = P->ptr(c, nrm); a.C = P->ptr(c, mid);
             return launch_gemm(a, PRO_NONE, EPI_BIAS_GELU, c.stream);
-        });
+        }, 1, "cnx.pwconv1");
         GemmArgs a2 = linear_args(cb.W2, cb.b2, Mrows, D, I);
         P->step({mid, xc}, [=](const RunCtx& c) {
             GemmArgs a = a2; a.A = P->ptr(c, mid); a.C = P->ptr(c, xc); a.R = P->ptr(c, xc); a.r_rstride = D; a.gamma = cb.gamma;
             return launch_gemm(a, PRO_NONE, EPI_BIAS_GAMMA_RES, c.stream);
-        });
+        }, 1, "cnx.pwconv2");
         if (keep && (i == 0 || i == ar.num_layers / 2 - 1 || i == ar.num_layers - 1)) {
             const int s = P->buf("bb.convnext." + std::to_string(i), (size_t)Mrows * D);
             P->step({xc, s}, [=](const RunCtx& c) {
@@ -794,7 +805,7 @@ static int build_decode(wt_plan* P) {
     P->step({xo, spec}, [=](const RunCtx& c) {
         GemmArgs a = ah; a.A = P->ptr(c, xo); a.C = P->ptr(c, spec); a.c_rstride = 2 * Kb; a.head_kb = Kb;
         return launch_gemm(a, PRO_NONE, EPI_HEAD, c.stream);
-    });
+    }, 1, "head.out");
     // ISTFT (spectral_ops.py:56-73): windowed inverse DFT + overlap-add + trim + envelope divide
     P->step({spec}, [=](const RunCtx& c) {
         GemmArgs a;
@@ -805,7 +816,7 @@ static int build_decode(wt_plan* P) {
         a.C = c.out_f; a.c_rstride = hop;
         a.ola_L = L; a.ola_hop = hop; a.ola_pad = (ar.n_fft - hop) / 2; a.ola_R = R; a.ola_wsq = M->wsq;
         return launch_gemm(a, PRO_NONE, EPI_OLA, c.stream);
-    });
+    }, 1, "head.istft");
     return 0;
 }
 
@@ -920,7 +931,12 @@ int wt_plan_create(const wt_model* m, int32_t kind, int32_t B, int64_t len, int3
     *out = P.release();
     return WT_OK;
 }
-void wt_plan_destroy(wt_plan* p) { delete p; }
+void wt_plan_destroy(wt_plan* p) {
+    if (!p) return;
+    for (auto& ev : p->ev_pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto& ev : p->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    delete p;
+}
 size_t wt_plan_workspace_bytes(const wt_plan* p) { return p ? p->ws_bytes : 0; }
 int64_t wt_plan_frames(const wt_plan* p) { return p ? p->L : 0; }
 int wt_plan_num_launches(const wt_plan* p) { return p ? p->n_launches : 0; }
@@ -944,8 +960,49 @@ int wt_plan_buffer_name(const wt_plan* p, int32_t index, const char** name) {
 
 static int run_plan(const wt_plan* p, const RunCtx& c) {
     WT_HIP_CHECK(hipSetDevice(p->model->device));
-    for (const auto& s : p->steps)
-        if (int rc = s(c)) return rc;
+    const bool timing = !p->timing_filter.empty();
+    for (size_t i = 0; i < p->steps.size(); ++i) {
+        const bool timed = timing && p->step_names[i].find(p->timing_filter) != std::string::npos;
+        std::pair<hipEvent_t, hipEvent_t> ev;
+        if (timed) {
+            if (!p->ev_free.empty()) { ev = p->ev_free.back(); p->ev_free.pop_back(); }
+            else { WT_HIP_CHECK(hipEventCreate(&ev.first)); WT_HIP_CHECK(hipEventCreate(&ev.second)); }
+            WT_HIP_CHECK(hipEventRecord(ev.first, c.stream));
+        }
+        if (int rc = p->steps[i](c)) return rc;
+        if (timed) {
+            WT_HIP_CHECK(hipEventRecord(ev.second, c.stream));
+            p->ev_pending.push_back(ev);
+        }
+    }
+    return WT_OK;
+}
+
+int wt_plan_num_steps(const wt_plan* p) { return p ? (int)p->steps.size() : 0; }
+int wt_plan_step_name(const wt_plan* p, int32_t index, const char** name) {
+    if (!p || index < 0 || index >= (int)p->step_names.size()) return WT_ERR_INVALID;
+    *name = p->step_names[index].c_str();
+    return WT_OK;
+}
+int wt_plan_set_timing(const wt_plan* p, const char* name_substr) {
+    if (!p) return WT_ERR_INVALID;
+    p->timing_filter = name_substr ? name_substr : "";
+    return WT_OK;
+}
+int wt_plan_read_timing(const wt_plan* p, double* total_ms, int64_t* launches, int32_t reset) {
+    if (!p) return WT_ERR_INVALID;
+    for (auto& ev : p->ev_pending) {
+        WT_HIP_CHECK(hipEventSynchronize(ev.second));
+        float ms = 0.f;
+        WT_HIP_CHECK(hipEventElapsedTime(&ms, ev.first, ev.second));
+        p->timing_ms += ms;
+        p->timing_n += 1;
+        p->ev_free.push_back(ev);
+    }
+    p->ev_pending.clear();
+    if (total_ms) *total_ms = p->timing_ms;
+    if (launches) *launches = p->timing_n;
+    if (reset) { p->timing_ms = 0.0; p->timing_n = 0; }
     return WT_OK;
 }
 

@@ -136,10 +136,13 @@ int launch_transpose(const float* in, float* out, int B, int R, int C, hipStream
 // decoder/models.py:15-16 Normalize = GroupNorm(32, C, eps=1e-6, affine): per (clip, group) mean and
 // biased variance over L x C/32 values, emitted as the per-(clip, channel) scale/shift
 //   y = x * (rstd*gamma[c]) + (beta[c] - mean*rstd*gamma[c])
-// that the consuming GEMM applies while staging its A operand (never a normalised copy in HBM).
+// (consumed by the row-norm pass for pos_net[5]); APPLY > 0 also writes the normalised (and
+// swish-activated) tensor once, which the following conv reads as a plain operand.
+template <int APPLY>   // 0: scale/shift only; 1: y = x*scale + shift; 2: y = swish(x*scale + shift)
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float* __restrict__ scale,
-                                                       float* __restrict__ shift, int L, int C, int cg, float eps) {
+                                                       float* __restrict__ shift, float* __restrict__ y, int L, int C,
+                                                       int cg, float eps) {
     __shared__ float red[4];
     __shared__ float s_mean, s_rstd;
     const int g = blockIdx.x, b = blockIdx.y;
@@ -175,12 +178,35 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
         scale[(long)b * C + c] = sc;
         shift[(long)b * C + c] = beta[c] - mean * sc;
     }
+    if (APPLY) {
+        float* yb = y + (long)b * L * C + g * cg;
+        const float rstd = s_rstd;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int t = i / cg, j = i - t * cg;
+            const float sc = rstd * gamma[g * cg + j];
+            float v = xb[(long)t * C + j] * sc + (beta[g * cg + j] - mean * sc);
+            if (APPLY == 2) v = v / (1.f + expf(-v));
+            yb[(long)t * C + j] = v;
+        }
+    }
 }
 
 int launch_gn_stats(const float* x, const float* gamma, const float* beta, float* scale, float* shift, int B, int L,
                     int C, int groups, float eps, hipStream_t s) {
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(groups, B), dim3(256), 0, s, x, gamma, beta, scale, shift, L, C,
-                       C / groups, eps);
+    hipLaunchKernelGGL(gn_stats_kernel<0>, dim3(groups, B), dim3(256), 0, s, x, gamma, beta, scale, shift,
+                       (float*)nullptr, L, C, C / groups, eps);
+    WT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_gn_apply(const float* x, const float* gamma, const float* beta, float* scale, float* shift, float* y,
+                    int swish, int B, int L, int C, int groups, float eps, hipStream_t s) {
+    if (swish)
+        hipLaunchKernelGGL(gn_stats_kernel<2>, dim3(groups, B), dim3(256), 0, s, x, gamma, beta, scale, shift, y, L, C,
+                           C / groups, eps);
+    else
+        hipLaunchKernelGGL(gn_stats_kernel<1>, dim3(groups, B), dim3(256), 0, s, x, gamma, beta, scale, shift, y, L, C,
+                           C / groups, eps);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -426,15 +452,15 @@ int launch_codes_to_features(const int64_t* codes, const float* embed, int K, in
 // order i,f,g,o, plus the skip add.  The recurrence is serial in time, so one launch = one
 // time step of BOTH layers, layer 1 running one step behind layer 0 (launch s: layer 0 step s,
 // layer 1 step s-1).  A workgroup owns 4 hidden units (their 16 gate rows, packed contiguously
-// at load time) for a tile of 64 clips; its 4 waves split K, v_mfma_f32_16x16x4_f32 does the
-// recurrent product, LDS adds the four K slices, and each thread then updates one (clip, unit)
+// at load time) for a tile of 64 clips; its 8 waves split K, v_mfma_f32_16x16x4_f32 does the
+// recurrent product, LDS adds the eight K slices, and each thread then updates one (clip, unit)
 // cell.  Weights stream from L2/Infinity Cache (4-8 MB per layer), h ping-pongs in HBM.
 typedef float f32x4acc __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
-__global__ __launch_bounds__(256) void lstm_step_kernel(const LstmArgs a, int s) {
-    __shared__ float red[4][64][17];
+__global__ __launch_bounds__(512) void lstm_step_kernel(const LstmArgs a, int s) {
+    __shared__ float red[8][64][17];
     const int H = a.H, B = a.B, L = a.L;
     const int nj = H / 4;
     const int layer = blockIdx.x >= nj ? 1 : 0;
@@ -446,33 +472,46 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmArgs a, int s)
     const int li = lane & 15, lk = lane >> 4;
 
     const int Ktot = layer ? 2 * H : H;
-    const int kw = Ktot / 4;                        // K slice of this wave
+    const int kw = Ktot / 8;                        // K slice of this wave (64 or 128)
     const int kbeg = wave * kw;
-    const float* W = (layer ? a.W1 : a.W0) + (long)(bj * 16 + li) * Ktot;
+    const float* W = (layer ? a.W1 : a.W0) + (long)(bj * 16 + li) * Ktot + kbeg + 4 * lk;
     // source of the K slice: layer 0: h0[t-1]; layer 1: [h0[t] | h1[t-1]]
     const float* hsrc;
     int koff;                                       // column offset inside hsrc rows
     if (!layer) { hsrc = a.h0 + (long)((t + 1) & 1) * B * H; koff = kbeg; }
     else if (kbeg < H) { hsrc = a.h0 + (long)(t & 1) * B * H; koff = kbeg; }
     else { hsrc = a.h1 + (long)((t + 1) & 1) * B * H; koff = kbeg - H; }
+    const float* hrow[4];
+    bool hok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int bb = b0 + i * 16 + li;
+        hok[i] = bb < B;
+        hrow[i] = hsrc + (long)(hok[i] ? bb : 0) * H + koff + 4 * lk;
+    }
 
     f32x4acc acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = (f32x4acc){0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < kw; k += 16) {
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(W + kbeg + k + 4 * lk);
-        f32x4 hv[4];
+    for (int k = 0; k < kw; k += 64) {
+        // one 64-deep chunk: every load is issued before the first MFMA (one L2 round trip per chunk)
+        f32x4 wv[4], hv[4][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int bb = b0 + i * 16 + li;
-            hv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (bb < B) hv[i] = *reinterpret_cast<const f32x4*>(hsrc + (long)bb * H + koff + k + 4 * lk);
-        }
+        for (int q = 0; q < 4; ++q) wv[q] = *reinterpret_cast<const f32x4*>(W + k + 16 * q);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[i][e], wv[e], acc[i], 0, 0, 0);
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(hrow[i] + k + 16 * q);
+                hv[i][q] = hok[i] ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[i][q][e], wv[q][e], acc[i], 0, 0, 0);
     }
     // C layout 16x16: col = lane & 15 (gate row), row = 4*(lane>>4) + reg (clip)
 #pragma unroll
@@ -481,6 +520,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmArgs a, int s)
         for (int r = 0; r < 4; ++r) red[wave][i * 16 + 4 * lk + r][li] = acc[i][r];
     __syncthreads();
 
+    if (threadIdx.x >= 256) return;
     const int br = threadIdx.x >> 2, jj = threadIdx.x & 3;
     const int bb = b0 + br;
     if (bb >= B) return;
@@ -489,7 +529,8 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmArgs a, int s)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int col = g * 4 + jj;
-        float v = (red[0][br][col] + red[1][br][col]) + (red[2][br][col] + red[3][br][col]);
+        float v = ((red[0][br][col] + red[1][br][col]) + (red[2][br][col] + red[3][br][col])) +
+                  ((red[4][br][col] + red[5][br][col]) + (red[6][br][col] + red[7][br][col]));
         if (!layer) v += a.xg0[((long)bb * L + t) * (4 * H) + bj * 16 + col];
         else v += a.b1[bj * 16 + col];
         g4[g] = v;
@@ -509,8 +550,9 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const LstmArgs a, int s)
 }
 
 int launch_lstm_step(const LstmArgs& a, int s, hipStream_t stream) {
+    if (a.H % 256 != 0) { set_error("lstm: hidden size must be a multiple of 256"); return -1; }
     dim3 grid(2 * (a.H / 4), (a.B + 63) / 64);
-    hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(256), 0, stream, a, s);
+    hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(512), 0, stream, a, s);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }
