@@ -41,15 +41,17 @@ WORKLOAD = {"hop600": "WavTokenizer-small-600-24k-4096 (40 tok/s), encode_infer+
 
 
 def cpu_baseline(arch_name, sd, clips_np):
-    """Oracle on the host cores: B=1 (BASELINE configs[0]) and a B=16 batch; returns the faster."""
+    """Oracle on the host cores.  torch's default thread count (= all cores) oversubscribes this
+    small model, so a few thread counts are tried on a B=16 batch and the fastest is kept; B=1
+    (BASELINE configs[0]) is timed at that count too.  ~30 s of CPU work in total."""
     from oracle.cpu_ref import OracleWavTokenizer
     from wavtokenizer_amd import NAMED_ARCHS
     orc = OracleWavTokenizer(NAMED_ARCHS[arch_name], sd)
     bw = torch.tensor([0])
-    cores = torch.get_num_threads()
-    results = {}
-    budget = time.time() + 40.0
-    for B, reps in ((1, 8), (16, 3)):
+    ncpu = os.cpu_count() or 1
+    deadline = time.time() + 60.0
+
+    def rate(B, reps):
         x = torch.from_numpy(clips_np[:B])
         with torch.inference_mode():
             f, _ = orc.encode_infer(x, bw)      # warm-up
@@ -60,15 +62,25 @@ def cpu_baseline(arch_name, sd, clips_np):
                 f, _ = orc.encode_infer(x, bw)
                 orc.decode(f, bw)
                 ts.append(time.perf_counter() - t0)
-                if time.time() > budget:
+                if time.time() > deadline:
                     break
         ts.sort()
-        results[B] = B * CLIP_SECONDS / ts[len(ts) // 2]
-    best_b = max(results, key=results.get)
-    return {"value": round(results[best_b], 2), "unit": "audio-s/s", "cores": cores, "kind": "port",
-            "sample": "oracle/cpu_ref.py (reference ATen op sequence, fp32) on %d torch threads; median round trip of "
-                      "B=1 x3s (8 reps): %.1f audio-s/s, B=16 x3s (3 reps): %.1f audio-s/s; value = the faster"
-                      % (cores, results[1], results[16])}
+        return B * CLIP_SECONDS / ts[len(ts) // 2]
+
+    tried = {}
+    for nt in sorted({min(ncpu, n) for n in (8, 16, 32, 64)}):     # all-cores (>64) only thrashes
+        torch.set_num_threads(nt)
+        tried[nt] = rate(16, 2)
+    best_nt = max(tried, key=tried.get)
+    torch.set_num_threads(best_nt)
+    r16 = rate(16, 3)
+    r1 = rate(1, 8)
+    value = max(r16, r1)
+    return {"value": round(value, 2), "unit": "audio-s/s", "cores": best_nt, "kind": "port",
+            "sample": "oracle/cpu_ref.py (the reference's ATen op sequence, fp32); thread sweep on B=16 x3s: %s; at %d threads "
+                      "median round trip B=16 x3s (3 reps): %.1f audio-s/s, B=1 x3s (8 reps): %.1f audio-s/s; value = the faster; "
+                      "host has %d logical CPUs"
+                      % (", ".join(f"{k}t={v:.1f}" for k, v in sorted(tried.items())), best_nt, r16, r1, ncpu)}
 
 
 def main():
@@ -163,7 +175,7 @@ def main():
                        "global_clips": world * B, "clip_seconds": CLIP_SECONDS, "frames_per_clip": L,
                        "weights": "random-init (synth seed 0)", "parallelism": f"clips sharded dp{world}",
                        "gather": "codes all_gather + waveform gather to rank 0 (RCCL) inside the step" if world > 1 and not args.no_gather else "none"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<128,128,2,2,PRO_NONE,EPI_BIAS_GELU> (ConvNeXt pwconv1)",
+            "roofline": {"bound": "mfma", "kernel": "wt::gemm_kernel<128,%d,..,PRO_NONE=0,EPI_BIAS_GELU=2> (ConvNeXt pwconv1 GEMM %dx%dx%d)" % (96 if args.arch == "hop600" and B == 64 else 128, Mrows, arch.intermediate_dim, arch.dim),
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
                          "flops_per_launch": flops, "avg_launch_ms": round(kern_ms, 4), "launches_timed": n_l.value,

@@ -36,7 +36,8 @@ enum Epi : int {
     EPI_OLA = 5,             // ISTFT overlap-add rows -> trimmed waveform / window envelope
     EPI_ARGMAX = 6,          // VQ: per-row argmax of -(xx - 2 acc + ee[n]) over this wave's columns
     EPI_SCALE = 7,           // C = alpha * acc
-    EPI_BIAS_ROW = 8         // C = acc + bias[m]
+    EPI_BIAS_ROW = 8,        // C = acc + bias[m]
+    EPI_BIAS_RES_ELU = 9     // C = elu((acc + bias[n]) + R[m][n])   (the only consumer applies ELU)
 };
 enum PadMode : int { PAD_ZERO = 0, PAD_REFLECT = 1 };
 
@@ -105,7 +106,7 @@ int launch_vq_finalize(const float* pval, const int* pidx, int nparts, const flo
 int launch_codes_to_features(const int64_t* codes, const float* embed, int K, int bins, int B, long L, int D,
                              float* feat_ncl, hipStream_t s);
 struct LstmArgs {
-    const float* xg0;     // [B][L][4H] layer-0 input projection (+ both biases), packed gate order
+    const float* xg0;     // [L][B][4H] (time-major) layer-0 input projection (+ both biases), packed gate order
     const float* W0;      // [4H][H]   packed W_hh_l0
     const float* W1;      // [4H][2H]  packed [W_ih_l1 | W_hh_l1]
     const float* b1;      // [4H]      packed b_ih_l1 + b_hh_l1
@@ -116,6 +117,7 @@ struct LstmArgs {
     const float* x;       // [B][L][H] skip input
     float* y;             // [B][L][H] output = h1 + x
     int B, L, H;
+    int elu_out;          // store elu(h1 + x): the only consumer is ELU -> conv (seanet.py:136-139)
 };
 int launch_lstm_step(const LstmArgs& a, int s, hipStream_t stream);
 int launch_convtr(const float* x, const float* w /*[k][Cin][Cout]*/, const float* bias, float* y, int B, int Tin,

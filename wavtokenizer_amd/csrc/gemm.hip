@@ -281,7 +281,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             const int n = n_w + j * 32 + col_l;
             if (n >= p.N) continue;
             float bn_ = 0.f, gm = 1.f;
-            if (EPI == EPI_BIAS || EPI == EPI_BIAS_RES || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GAMMA_RES)
+            if (EPI == EPI_BIAS || EPI == EPI_BIAS_RES || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GAMMA_RES ||
+                EPI == EPI_BIAS_RES_ELU)
                 bn_ = p.bias ? p.bias[n] : 0.f;
             if (EPI == EPI_BIAS_GAMMA_RES) gm = p.gamma[n];
 #pragma unroll
@@ -293,6 +294,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                     Cg[(long)m * p.c_rstride + n] = v + bn_;
                 } else if (EPI == EPI_BIAS_RES) {
                     Cg[(long)m * p.c_rstride + n] = (v + bn_) + p.R[(long)m * p.r_rstride + n];
+                } else if (EPI == EPI_BIAS_RES_ELU) {
+                    Cg[(long)m * p.c_rstride + n] = elu1((v + bn_) + p.R[(long)m * p.r_rstride + n]);
                 } else if (EPI == EPI_BIAS_GELU) {
                     Cg[(long)m * p.c_rstride + n] = gelu_erf(v + bn_);
                 } else if (EPI == EPI_BIAS_GAMMA_RES) {
@@ -363,14 +366,15 @@ static int launch_tiled(const GemmArgs& a, hipStream_t s) {
     } else {
         if (a.N <= 32) return launch_one<128, 32, 4, 1, PRO, EPI>(a, s);
         if (a.N <= 64) return launch_one<128, 64, 2, 2, PRO, EPI>(a, s);
-        if (a.N % 96 == 0) {
-            // 512 workgroup slots (2 per CU): take 128x96 tiles when the last round of 128x128
-            // tiles would leave most of the chip idle (e.g. 7680x768: 360 tiles on 512 slots)
+        {
+            // 512 workgroup slots (2 per CU).  Cost of a tiling ~ rounds of slots x tile width; take
+            // 128x96 tiles when 128x128 would leave most of the chip idle in its last round
+            // (e.g. 7680x768: 360 tiles on 512 slots).  Measured: tools/gemm_bench.py.
             const long tm = (a.M + 127) / 128;
-            const long t128 = tm * ((a.N + 127) / 128) * a.nz, t96 = tm * (a.N / 96) * a.nz;
-            const double r128 = (double)t128 / 512.0, r96 = (double)t96 / 512.0;
-            const double eff128 = r128 / std::ceil(r128), eff96 = 0.97 * r96 / std::ceil(r96);
-            if (eff96 > eff128) return launch_one<128, 96, 4, 1, PRO, EPI>(a, s);
+            const long t128 = tm * ((a.N + 127) / 128) * a.nz, t96 = tm * ((a.N + 95) / 96) * a.nz;
+            const double c128 = std::ceil((double)t128 / 512.0) * 128.0;
+            const double c96 = std::ceil((double)t96 / 512.0) * 96.0 / 0.97;
+            if (c96 < c128) return launch_one<128, 96, 4, 1, PRO, EPI>(a, s);
         }
         return launch_one<128, 128, 2, 2, PRO, EPI>(a, s);
     }
@@ -412,10 +416,8 @@ int launch_gemm(const GemmArgs& a, int pro, int epi, hipStream_t s) {
     WT_CASE(PRO_NONE, EPI_BIAS)
     WT_CASE(PRO_ELU, EPI_BIAS)
     WT_CASE(PRO_ELU, EPI_BIAS_RES)
+    WT_CASE(PRO_ELU, EPI_BIAS_RES_ELU)
     WT_CASE(PRO_NONE, EPI_BIAS_RES)
-    WT_CASE(PRO_AFFINE_SWISH, EPI_BIAS)
-    WT_CASE(PRO_AFFINE_SWISH, EPI_BIAS_RES)
-    WT_CASE(PRO_AFFINE, EPI_BIAS)
     WT_CASE(PRO_NONE, EPI_BIAS_GELU)
     WT_CASE(PRO_NONE, EPI_BIAS_GAMMA_RES)
     WT_CASE(PRO_NONE, EPI_HEAD)

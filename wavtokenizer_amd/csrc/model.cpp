@@ -549,7 +549,7 @@ static GemmArgs linear_args(const float* W, const float* bias, long M, int N, in
 
 // SEANetResnetBlock (seanet.py:62-63): y = shortcut(x) + conv1(elu(conv3(elu(x)))); returns y's buffer
 static int plan_resblock(wt_plan* P, const ConvW& c3, const ConvW& c1, const ConvW& sc, int B, long T, int xin,
-                         const std::string& name) {
+                         const std::string& name, bool elu_out = false) {
     const int C = sc.cout;
     const int h = P->buf(name + ".h", (size_t)B * T * (C / 2));
     const int y = P->buf(name, (size_t)B * T * C);
@@ -566,17 +566,21 @@ static int plan_resblock(wt_plan* P, const ConvW& c3, const ConvW& c1, const Con
     GemmArgs a1 = sconv_args(c1, B, T, 1, 1);
     P->step({h, y}, [=](const RunCtx& c) {
         GemmArgs a = a1; a.A = P->ptr(c, h); a.C = P->ptr(c, y); a.R = P->ptr(c, y); a.r_rstride = C;
-        return launch_gemm(a, PRO_ELU, EPI_BIAS_RES, c.stream);
+        return launch_gemm(a, PRO_ELU, elu_out ? EPI_BIAS_RES_ELU : EPI_BIAS_RES, c.stream);
     });
     return y;
 }
 
 // SLSTM (lstm.py:31-39) on x [B][L][H]; returns y = lstm(x) + x
-static int plan_lstm(wt_plan* P, const LstmW& w, int B, int L, int H, int xin, const std::string& name) {
+static int plan_lstm(wt_plan* P, const LstmW& w, int B, int L, int H, int xin, const std::string& name,
+                     bool elu_out = false) {
     const int xg = P->buf(name + ".xg", (size_t)B * L * 4 * H);
     const int st = P->buf(name + ".state", (size_t)6 * B * H);   // h0[2], h1[2], c0, c1
     const int y = P->buf(name, (size_t)B * L * H);
+    // input projection written time-major ([L][B][4H]) so each recurrent step reads one contiguous
+    // slab: the gather treats a time step as the "clip" (stride H) and the clip as the row (stride L*H)
     GemmArgs ax = linear_args(w.Wih0, w.b0, (long)B * L, 4 * H, H);
+    ax.T_in = B; ax.T_out = B; ax.a_bstride = H; ax.a_rstride = (long)L * H;
     P->step({xin, xg}, [=](const RunCtx& c) {
         GemmArgs a = ax; a.A = P->ptr(c, xin); a.C = P->ptr(c, xg);
         return launch_gemm(a, PRO_NONE, EPI_BIAS, c.stream);
@@ -587,7 +591,7 @@ static int plan_lstm(wt_plan* P, const LstmW& w, int B, int L, int H, int xin, c
         LstmArgs la;
         la.xg0 = P->ptr(c, xg); la.W0 = w.W0; la.W1 = w.W1; la.b1 = w.b1;
         la.h0 = s; la.h1 = s + (size_t)2 * B * H; la.c0 = s + (size_t)4 * B * H; la.c1 = s + (size_t)5 * B * H;
-        la.x = P->ptr(c, xin); la.y = P->ptr(c, y); la.B = B; la.L = L; la.H = H;
+        la.x = P->ptr(c, xin); la.y = P->ptr(c, y); la.B = B; la.L = L; la.H = H; la.elu_out = elu_out ? 1 : 0;
         for (int t = 0; t <= L; ++t)
             if (int rc = launch_lstm_step(la, t, c.stream)) return rc;
         return 0;
@@ -603,30 +607,33 @@ static int build_encode(wt_plan* P) {
     P->step({x}, [=](const RunCtx& c) {
         return launch_conv_first(c.in_f, M->e0_w, M->e0_b, P->ptr(c, x), B, T, M->e0_k, M->e0_c, c.stream);
     });
+    // ELU is applied once by the producer wherever its only consumer is "ELU -> conv" (resblock
+    // output -> down conv, LSTM output -> last conv); with KEEP_STAGES the taps stay raw instead
+    const bool fuse_elu = !(P->flags & WT_PLAN_FLAG_KEEP_STAGES);
     long Tc = T;
     int idx = 1;
     for (const ResStage& st : M->stages) {
-        x = plan_resblock(P, st.c3, st.c1, st.sc, B, Tc, x, "enc." + std::to_string(idx));
+        x = plan_resblock(P, st.c3, st.c1, st.sc, B, Tc, x, "enc." + std::to_string(idx), fuse_elu);
         GemmArgs ad = sconv_args(st.down, B, Tc, st.r, 1);
         const int y = P->buf("enc." + std::to_string(idx + 2), (size_t)B * ad.T_out * st.down.cout);
         const int xin = x;
         P->step({xin, y}, [=](const RunCtx& c) {
             GemmArgs a = ad; a.A = P->ptr(c, xin); a.C = P->ptr(c, y);
-            return launch_gemm(a, PRO_ELU, EPI_BIAS, c.stream);
+            return launch_gemm(a, fuse_elu ? PRO_NONE : PRO_ELU, EPI_BIAS, c.stream);
         });
         x = y; Tc = ad.T_out; idx += 3;
     }
     const int L = (int)Tc;
     if (L != P->L) { set_error("internal: frame count mismatch"); return WT_ERR_INVALID; }
     const int H = M->H;
-    x = plan_lstm(P, M->enc_lstm, B, L, H, x, "enc." + std::to_string(idx));
+    x = plan_lstm(P, M->enc_lstm, B, L, H, x, "enc." + std::to_string(idx), fuse_elu);
     GemmArgs af = sconv_args(M->enc_final, B, L, 1, 1);
     const int emb = P->buf("enc." + std::to_string(idx + 2), (size_t)B * L * 512);
     {
         const int xin = x;
         P->step({xin, emb}, [=](const RunCtx& c) {
             GemmArgs a = af; a.A = P->ptr(c, xin); a.C = P->ptr(c, emb);
-            return launch_gemm(a, PRO_ELU, EPI_BIAS, c.stream);
+            return launch_gemm(a, fuse_elu ? PRO_NONE : PRO_ELU, EPI_BIAS, c.stream);
         });
     }
     // ---- VQ (core_vq.py:175-183, 206-231)

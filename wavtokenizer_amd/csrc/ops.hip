@@ -490,6 +490,21 @@ __global__ __launch_bounds__(512) void lstm_step_kernel(const LstmArgs a, int s)
         hrow[i] = hsrc + (long)(hok[i] ? bb : 0) * H + koff + 4 * lk;
     }
 
+    // cell-update operands (threads 0..255: one (clip, unit) each) are fetched now, under the MFMA loop
+    const int br = (threadIdx.x >> 2) & 63, jj = threadIdx.x & 3;
+    const int cb = b0 + br;
+    const bool cell = threadIdx.x < 256 && cb < B;
+    const int j = bj * 4 + jj;
+    float gin[4] = {0.f, 0.f, 0.f, 0.f}, c_prev = 0.f, x_skip = 0.f;
+    float* cst = (layer ? a.c1 : a.c0) + (long)(cell ? cb : 0) * H + j;
+    if (cell) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            gin[g] = layer ? a.b1[bj * 16 + g * 4 + jj] : a.xg0[((long)t * B + cb) * (4 * H) + bj * 16 + g * 4 + jj];
+        c_prev = *cst;
+        if (layer) x_skip = a.x[((long)cb * L + t) * H + j];
+    }
+
     f32x4acc acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = (f32x4acc){0.f, 0.f, 0.f, 0.f};
@@ -520,32 +535,24 @@ __global__ __launch_bounds__(512) void lstm_step_kernel(const LstmArgs a, int s)
         for (int r = 0; r < 4; ++r) red[wave][i * 16 + 4 * lk + r][li] = acc[i][r];
     __syncthreads();
 
-    if (threadIdx.x >= 256) return;
-    const int br = threadIdx.x >> 2, jj = threadIdx.x & 3;
-    const int bb = b0 + br;
-    if (bb >= B) return;
-    const int j = bj * 4 + jj;
+    if (!cell) return;
     float g4[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int col = g * 4 + jj;
-        float v = ((red[0][br][col] + red[1][br][col]) + (red[2][br][col] + red[3][br][col])) +
-                  ((red[4][br][col] + red[5][br][col]) + (red[6][br][col] + red[7][br][col]));
-        if (!layer) v += a.xg0[((long)bb * L + t) * (4 * H) + bj * 16 + col];
-        else v += a.b1[bj * 16 + col];
-        g4[g] = v;
+        g4[g] = (((red[0][br][col] + red[1][br][col]) + (red[2][br][col] + red[3][br][col])) +
+                 ((red[4][br][col] + red[5][br][col]) + (red[6][br][col] + red[7][br][col]))) + gin[g];
     }
-    float* cst = (layer ? a.c1 : a.c0) + (long)bb * H + j;
     const float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]), gg = tanhf(g4[2]), og = sigmoidf_(g4[3]);
-    const float c = fg * (*cst) + ig * gg;
+    const float c = fg * c_prev + ig * gg;
     const float h = og * tanhf(c);
     *cst = c;
     if (!layer) {
-        a.h0[(long)(t & 1) * B * H + (long)bb * H + j] = h;
+        a.h0[(long)(t & 1) * B * H + (long)cb * H + j] = h;
     } else {
-        a.h1[(long)(t & 1) * B * H + (long)bb * H + j] = h;
-        const long o = ((long)bb * L + t) * H + j;
-        a.y[o] = h + a.x[o];                        // lstm.py:37-38 skip
+        a.h1[(long)(t & 1) * B * H + (long)cb * H + j] = h;
+        const float yv = h + x_skip;                    // lstm.py:37-38 skip
+        a.y[((long)cb * L + t) * H + j] = a.elu_out ? (yv > 0.f ? yv : expm1f(yv)) : yv;
     }
 }
 
