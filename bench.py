@@ -83,6 +83,24 @@ def cpu_baseline(arch_name, sd, clips_np):
                       % (", ".join(f"{k}t={v:.1f}" for k, v in sorted(tried.items())), best_nt, r16, r1, ncpu)}
 
 
+def pmc_traffic(arch_name, B):
+    """Bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate
+    FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected: tools/summarize_profile.py); None if there is
+    no summary for this workload.  PMC counters cannot be read from inside the timed process."""
+    import glob
+    if arch_name != "hop600" or B != 64:
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        kernels = json.load(f)["kernels"]
+    for name, v in kernels.items():
+        if "gemm_kernel" in name and name.rstrip().endswith(", 0, 2>(wt::GemmArgs)"):
+            return v["traffic_bytes_per_launch"]
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,15 +140,14 @@ def main():
     bw = torch.tensor([0])
     L = arch.frames(T)
 
-    codes_all = torch.empty((world, 1, B, L), dtype=torch.int64, device=dev) if world > 1 else None
-    wav_all = [torch.empty((B, L * arch.hop_length), device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    from wavtokenizer_amd.sharding import gather_codes, gather_waveforms
 
     def step():
         feats, codes = model.encode_infer(wav, bandwidth_id=bw)
         out = model.decode(feats, bandwidth_id=bw)
         if world > 1 and not args.no_gather:
-            dist.all_gather_into_tensor(codes_all, codes)            # 8*L bytes per clip
-            dist.gather(out, wav_all, dst=0)                         # waveforms to rank 0
+            codes = gather_codes(codes, dist, world)                 # 8*L bytes per clip, to every rank
+            out = gather_waveforms(out, dist, world, rank, dst=0)    # waveforms to rank 0
         return codes, out
 
     def barrier():
@@ -177,7 +194,7 @@ def main():
                        "gather": "codes all_gather + waveform gather to rank 0 (RCCL) inside the step" if world > 1 and not args.no_gather else "none"},
             "roofline": {"bound": "mfma", "kernel": "wt::gemm_kernel<128,%d,..,PRO_NONE=0,EPI_BIAS_GELU=2> (ConvNeXt pwconv1 GEMM %dx%dx%d)" % (96 if args.arch == "hop600" and B == 64 else 128, Mrows, arch.intermediate_dim, arch.dim),
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(args.arch, B),
                          "flops_per_launch": flops, "avg_launch_ms": round(kern_ms, 4), "launches_timed": n_l.value,
                          "end_to_end_tflops": round(e2e_tflops, 2),
                          "end_to_end_frac": round(e2e_tflops / PEAK_FP32_MFMA_TFLOPS, 4)},

@@ -1,0 +1,123 @@
+"""CPU: host-side logic — config parsing, state-dict layout, C-ABI exports, sharding over gloo."""
+import ctypes
+import os
+import re
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tests.util import manifest, ROOT
+
+
+def test_yaml_configs_parse(tmp_path):
+    from wavtokenizer_amd.config import arch_from_yaml_dict, ARCH_HOP600, ARCH_HOP320
+    for arch in (ARCH_HOP600, ARCH_HOP320):
+        node = {"model": {"init_args": {
+            "feature_extractor": {"class_path": "decoder.feature_extractors.EncodecFeatures",
+                                  "init_args": {"encodec_model": "encodec_24khz", "bandwidths": list(arch.bandwidths),
+                                                "num_quantizers": 1, "dowmsamples": list(arch.ratios), "vq_bins": 4096}},
+            "backbone": {"class_path": "decoder.models.VocosBackbone",
+                         "init_args": {"input_channels": 512, "dim": 768, "intermediate_dim": 2304, "num_layers": 12,
+                                       "adanorm_num_embeddings": 4}},
+            "head": {"class_path": "decoder.heads.ISTFTHead",
+                     "init_args": {"dim": 768, "n_fft": arch.n_fft, "hop_length": arch.hop_length, "padding": "same"}}}}}
+        assert arch_from_yaml_dict(node) == arch
+        assert arch.hop == arch.hop_length
+    assert ARCH_HOP600.frames(72000) == 120 and ARCH_HOP320.frames(61920) == 194      # wavtokenizer.txt:157
+    bad = {"model": {"init_args": {"feature_extractor": {"class_path": "x.MelSpectrogramFeatures"}, "backbone": {}, "head": {}}}}
+    with pytest.raises(ValueError):
+        arch_from_yaml_dict(bad)
+
+
+@pytest.mark.parametrize("name", ["hop600", "hop320"])
+def test_state_dict_layout_matches_reference(name):
+    """Keys and shapes equal the reference module's own state_dict (dumped into the manifest)."""
+    from wavtokenizer_amd.state_spec import full_state_spec
+    from wavtokenizer_amd.config import NAMED_ARCHS
+    want = manifest()["archs"][name]["ref_state_keys"]
+    got = {k: list(v) for k, v in full_state_spec(NAMED_ARCHS[name]).items()}
+    assert got == want
+
+
+def test_library_exports_the_whole_c_abi():
+    """libwavtok_hip.so loads and exports every function include/wavtokenizer_amd.h declares."""
+    from wavtokenizer_amd import _capi
+    header = open(os.path.join(ROOT, "include", "wavtokenizer_amd.h")).read()
+    declared = set(re.findall(r"\b(wt_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_capi.EXPORTS), declared ^ set(_capi.EXPORTS)
+    for sym in declared:
+        assert getattr(_capi.lib, sym) is not None
+    assert b"gfx950" in _capi.lib.wt_version()
+
+
+def test_module_tree_and_cpu_refusal():
+    from wavtokenizer_amd import WavTokenizer, ARCH_HOP600
+    m = WavTokenizer.from_arch(ARCH_HOP600)
+    fe = m.feature_extractor
+    assert fe.encodec.quantizer.bins == 4096 and fe.bandwidths == [6.6, 6.6, 6.6, 6.6]
+    assert tuple(fe.encodec.quantizer.vq.layers[0].codebook.shape) == (4096, 512)
+    assert callable(fe.encodec.encoder) and callable(fe.encodec.decoder) and callable(m.backbone)
+    assert len(m.state_dict()) == 289
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m.encode_infer(torch.zeros(1, 600), bandwidth_id=torch.tensor([0]))
+
+
+def test_shard_bounds_cover_everything():
+    from wavtokenizer_amd.sharding import shard_bounds
+    for n in (1, 7, 64, 512, 513):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+class _FakeCodec:
+    """Stands in for the GPU model in the gloo test: per-clip, deterministic, batch-independent."""
+    def encode_infer(self, wav, bandwidth_id=None):
+        codes = (wav[:, ::600].abs() * 4095).long().clamp_(0, 4095).unsqueeze(0)
+        return wav[:, None, ::600].repeat(1, 512, 1), codes
+
+    def decode(self, feats, bandwidth_id=None):
+        return feats[:, 0, :].repeat_interleave(600, dim=1)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_clips, q):
+    import torch.distributed as dist
+    from wavtokenizer_amd.sharding import roundtrip_sharded
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(0)
+    wav = torch.rand(n_clips, 3000, generator=g)
+    codes, out = roundtrip_sharded(_FakeCodec(), wav, torch.tensor([0]), dist, rank, world, dst=0)
+    m = _FakeCodec()
+    f, c = m.encode_infer(wav)
+    ok = torch.equal(codes, c) and (rank != 0 or torch.equal(out, m.decode(f))) and (rank == 0 or out is None)
+    q.put((rank, bool(ok), tuple(codes.shape)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_clips", [8, 7])
+def test_sharded_roundtrip_world2_gloo(n_clips):
+    """N > 1 path: two ranks over gloo, even and uneven shards; the gathers rebuild the clip order."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_clips, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
+    assert all(shape == (1, n_clips, 5) for _, _, shape in res)

@@ -77,6 +77,7 @@ struct GemmArgs {
     float* vq_pval = nullptr;         // [M][vq_nparts]
     int*   vq_pidx = nullptr;
     int vq_nparts = 0;
+    int group_m = 8;      // tile scheduling group (set by launch_gemm)
 };
 
 enum TileCfg : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2, TILE_64x64 = 3 };

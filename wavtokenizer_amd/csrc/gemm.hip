@@ -55,7 +55,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
     const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int bm = tile / tiles_n, bn = tile % tiles_n;
+    // grouped order: 8 row-tiles x all column-tiles at a time, column-major inside the group, so the
+    // ~64 tiles an XCD runs together share 8 A panels and 8 W panels (its 4 MiB L2 holds them)
+    const int GM = p.group_m;
+    const int per_group = GM * tiles_n;
+    const int grp = tile / per_group;
+    const int first_m = grp * GM;
+    const int gsz = tiles_m - first_m < GM ? tiles_m - first_m : GM;
+    const int in_grp = tile - grp * per_group;
+    const int bm = first_m + in_grp % gsz, bn = in_grp / gsz;
     const int z = blockIdx.z;
 
     const float* __restrict__ Ag = p.A + (long)z * p.zA;
@@ -384,6 +392,19 @@ int gemm_vq_parts(int N) { return ((N + 127) / 128) * 2; }
 
 int gemm_init() { return 0; }
 
+// row-tiles per scheduling group (see the tile remap in the kernel)
+static int pick_group_m(const GemmArgs& a) {
+    static int env = -2;
+    if (env == -2) { const char* e = getenv("WT_GEMM_GM"); env = e ? atoi(e) : -1; }
+    if (env > 0) return env;
+    // An XCD runs ~64 tiles at once and its 4 MiB L2 only holds what they stream in lockstep, so
+    // fabric reads ~ sum over such waves of (distinct A panels + distinct W panels).  With many column
+    // tiles an 8 x 8 wave is the minimum; with <= 8 column tiles a full row of tiles already is one
+    // (FETCH_SIZE sweep: tools/gm_sweep.sh, profiles/r01_gm_sweep.txt).
+    const int bn = a.N <= 32 ? 32 : (a.N <= 64 ? 64 : 96);
+    return (a.N + bn - 1) / bn > 8 ? 8 : 1;
+}
+
 static int check_args(const GemmArgs& a) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) { set_error("gemm: empty problem"); return -1; }
     if (a.K % 4 != 0 || a.Cin % 4 != 0) { set_error("gemm: K and Cin must be multiples of 4"); return -1; }
@@ -408,8 +429,10 @@ static int check_args(const GemmArgs& a) {
     return 0;
 }
 
-int launch_gemm(const GemmArgs& a, int pro, int epi, hipStream_t s) {
-    if (int rc = check_args(a)) return rc;
+int launch_gemm(const GemmArgs& a_in, int pro, int epi, hipStream_t s) {
+    if (int rc = check_args(a_in)) return rc;
+    GemmArgs a = a_in;
+    a.group_m = pick_group_m(a);
 #define WT_CASE(P, E) \
     if (pro == P && epi == E) return launch_tiled<P, E>(a, s);
     // the (prologue, epilogue) pairs the plans use

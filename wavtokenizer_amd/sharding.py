@@ -1,0 +1,66 @@
+"""Clip sharding across the GPUs of one node.
+
+Clips are independent (no cross-clip op exists on the path), so a batch is cut into contiguous
+blocks, one per rank; weights are replicated; nothing is exchanged while encoding/decoding.  The
+only collective is the end-of-step gather: codes to every rank (8*L bytes per clip) and, when one
+rank wants the audio, waveforms to that rank.  One process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+
+
+def shard_bounds(n_clips: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [lo, hi) block of clips for `rank`; sizes differ by at most one."""
+    base, rem = divmod(n_clips, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def _pad_rows(x: torch.Tensor, dim: int, n: int) -> torch.Tensor:
+    if x.shape[dim] == n:
+        return x.contiguous()
+    shape = list(x.shape)
+    shape[dim] = n - x.shape[dim]
+    return torch.cat([x, x.new_zeros(shape)], dim=dim).contiguous()
+
+
+def gather_codes(codes_local: torch.Tensor, dist, world: int, counts: Optional[List[int]] = None) -> torch.Tensor:
+    """codes_local (K, b_r, L) -> (K, sum b_r, L) on every rank, ranks in order.  Collectives need equal
+    sizes, so uneven shards are zero-padded to the largest and trimmed after the gather."""
+    if world == 1:
+        return codes_local
+    K, b, L = codes_local.shape
+    counts = counts or [b] * world
+    bmax = max(counts)
+    out = torch.empty((world * K, bmax, L), dtype=codes_local.dtype, device=codes_local.device)
+    dist.all_gather_into_tensor(out, _pad_rows(codes_local, 1, bmax))     # rank-major concatenation on dim 0
+    out = out.view(world, K, bmax, L)
+    return torch.cat([out[r, :, :counts[r]] for r in range(world)], dim=1)
+
+
+def gather_waveforms(wav_local: torch.Tensor, dist, world: int, rank: int, dst: int = 0,
+                     counts: Optional[List[int]] = None) -> Optional[torch.Tensor]:
+    """wav_local (b_r, T) -> (sum b_r, T) on rank `dst`, None elsewhere."""
+    if world == 1:
+        return wav_local
+    b, T = wav_local.shape
+    counts = counts or [b] * world
+    bmax = max(counts)
+    bufs = [torch.empty((bmax, T), dtype=wav_local.dtype, device=wav_local.device) for _ in range(world)] if rank == dst else None
+    dist.gather(_pad_rows(wav_local, 0, bmax), bufs, dst=dst)
+    return torch.cat([bufs[r][:counts[r]] for r in range(world)], dim=0) if rank == dst else None
+
+
+def roundtrip_sharded(model, wav_all: torch.Tensor, bandwidth_id: torch.Tensor, dist, rank: int, world: int,
+                      dst: int = 0):
+    """encode_infer + decode of this rank's block of `wav_all` (B, T); returns (codes of all clips on every
+    rank, waveforms of all clips on rank dst)."""
+    lo, hi = shard_bounds(wav_all.shape[0], rank, world)
+    counts = [shard_bounds(wav_all.shape[0], r, world)[1] - shard_bounds(wav_all.shape[0], r, world)[0] for r in range(world)]
+    feats, codes = model.encode_infer(wav_all[lo:hi].contiguous(), bandwidth_id=bandwidth_id)
+    out = model.decode(feats, bandwidth_id=bandwidth_id)
+    return gather_codes(codes, dist, world, counts), gather_waveforms(out, dist, world, rank, dst, counts)
