@@ -121,6 +121,23 @@ struct LstmArgs {
     int elu_out;          // store elu(h1 + x): the only consumer is ELU -> conv (seanet.py:136-139)
 };
 int launch_lstm_step(const LstmArgs& a, int s, hipStream_t stream);
+struct ResblockArgs {
+    const float* x;       // [B][T][C] raw block input (unused when wav is set)
+    const float* wav;     // optional [B][T]: fold SEANetEncoder model[0] (k=7, 1 -> 32) into the tile load
+    const float* e0_w;    // [7][32]
+    const float* e0_b;    // [32]
+    const float* W3;      // [C/2][3][C]
+    const float* b3;
+    const float* W1;      // [C][C/2]
+    const float* b1;
+    const float* Ws;      // [C][C]
+    const float* bs;
+    float* y;             // [B][T][C]
+    int B, T, C;
+    int elu_out;          // store elu(y) (the only consumer is ELU -> down conv)
+};
+bool resblock_fusable(int C);
+int launch_resblock(const ResblockArgs& a, hipStream_t s);
 int launch_convtr(const float* x, const float* w /*[k][Cin][Cout]*/, const float* bias, float* y, int B, int Tin,
                   int Cin, int Cout, int k, int stride, int elu_in, hipStream_t s);
 

@@ -549,8 +549,22 @@ static GemmArgs linear_args(const float* W, const float* bias, long M, int N, in
 
 // SEANetResnetBlock (seanet.py:62-63): y = shortcut(x) + conv1(elu(conv3(elu(x)))); returns y's buffer
 static int plan_resblock(wt_plan* P, const ConvW& c3, const ConvW& c1, const ConvW& sc, int B, long T, int xin,
-                         const std::string& name, bool elu_out = false) {
+                         const std::string& name, bool elu_out = false, const wt_model* e0 = nullptr) {
     const int C = sc.cout;
+    if (resblock_fusable(C) && !(P->flags & WT_PLAN_FLAG_KEEP_STAGES)) {
+        // one fused kernel (resblock.hip); with e0 set, xin is unused and the tile is built from the waveform
+        const int y = P->buf(name, (size_t)B * T * C);
+        P->step({e0 ? -1 : xin, y}, [=](const RunCtx& c) {
+            ResblockArgs a{};
+            a.x = e0 ? nullptr : P->ptr(c, xin);
+            a.wav = e0 ? c.in_f : nullptr;
+            a.e0_w = e0 ? e0->e0_w : nullptr; a.e0_b = e0 ? e0->e0_b : nullptr;
+            a.W3 = c3.w; a.b3 = c3.b; a.W1 = c1.w; a.b1 = c1.b; a.Ws = sc.w; a.bs = sc.b;
+            a.y = P->ptr(c, y); a.B = B; a.T = (int)T; a.C = C; a.elu_out = elu_out ? 1 : 0;
+            return launch_resblock(a, c.stream);
+        }, 1, "resblock.fused");
+        return y;
+    }
     const int h = P->buf(name + ".h", (size_t)B * T * (C / 2));
     const int y = P->buf(name, (size_t)B * T * C);
     GemmArgs a3 = sconv_args(c3, B, T, 1, 1);
@@ -603,17 +617,25 @@ static int build_encode(wt_plan* P) {
     const wt_model* M = P->model;
     const int B = P->B;
     const long T = P->T;
-    int x = P->buf("enc.0", (size_t)B * T * M->e0_c);
-    P->step({x}, [=](const RunCtx& c) {
-        return launch_conv_first(c.in_f, M->e0_w, M->e0_b, P->ptr(c, x), B, T, M->e0_k, M->e0_c, c.stream);
-    });
+    // the first conv is folded into the fused stage-1 resblock unless stage taps are kept
+    const bool fold_e0 = !(P->flags & WT_PLAN_FLAG_KEEP_STAGES) && !M->stages.empty() && M->stages[0].C == 32 &&
+                         M->e0_k == 7 && resblock_fusable(32);
+    int x = -1;
+    if (!fold_e0) {
+        x = P->buf("enc.0", (size_t)B * T * M->e0_c);
+        const int x0 = x;
+        P->step({x0}, [=](const RunCtx& c) {
+            return launch_conv_first(c.in_f, M->e0_w, M->e0_b, P->ptr(c, x0), B, T, M->e0_k, M->e0_c, c.stream);
+        });
+    }
     // ELU is applied once by the producer wherever its only consumer is "ELU -> conv" (resblock
     // output -> down conv, LSTM output -> last conv); with KEEP_STAGES the taps stay raw instead
     const bool fuse_elu = !(P->flags & WT_PLAN_FLAG_KEEP_STAGES);
     long Tc = T;
     int idx = 1;
     for (const ResStage& st : M->stages) {
-        x = plan_resblock(P, st.c3, st.c1, st.sc, B, Tc, x, "enc." + std::to_string(idx), fuse_elu);
+        x = plan_resblock(P, st.c3, st.c1, st.sc, B, Tc, x, "enc." + std::to_string(idx), fuse_elu,
+                          (idx == 1 && fold_e0) ? M : nullptr);
         GemmArgs ad = sconv_args(st.down, B, Tc, st.r, 1);
         const int y = P->buf("enc." + std::to_string(idx + 2), (size_t)B * ad.T_out * st.down.cout);
         const int xin = x;
