@@ -32,7 +32,8 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     return base + idx;
 }
 
-__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+// elu: exp(x) - 1 as ATen's CPU kernel evaluates it; __expf keeps the absolute error ~1e-7
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
 __device__ __forceinline__ float swish(float y) { return y / (1.f + expf(-y)); }
 __device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.f + erff(x * 0.70710678118654752440f)); }
 

@@ -552,7 +552,7 @@ __global__ __launch_bounds__(512) void lstm_step_kernel(const LstmArgs a, int s)
     } else {
         a.h1[(long)(t & 1) * B * H + (long)cb * H + j] = h;
         const float yv = h + x_skip;                    // lstm.py:37-38 skip
-        a.y[((long)cb * L + t) * H + j] = a.elu_out ? (yv > 0.f ? yv : expm1f(yv)) : yv;
+        a.y[((long)cb * L + t) * H + j] = a.elu_out ? (yv > 0.f ? yv : __expf(yv) - 1.f) : yv;
     }
 }
 

@@ -5,8 +5,8 @@
 //
 // Unfused these stages are HBM- and launch-bound GEMMs with K = 16..192 (stage 1 moves 5.3 GB per
 // 64-clip step where 0.6 GB is compulsory).  Here a workgroup keeps a 128-frame tile of x in LDS
-// (raw and ELU'd, with the +-1 frame halo of the k=3 conv, reflect-resolved at clip edges), each of
-// its 4 waves owns 32 frames and runs both contractions on the fp32 matrix pipe
+// (with the +-1 frame halo of the k=3 conv, reflect-resolved at clip edges), each of
+// its waves owns 32 frames and runs both contractions on the fp32 matrix pipe
 // (v_mfma_f32_32x32x2_f32); conv1 is frame-local, so the hidden activations never leave the
 // wave's own LDS rows.  Weights (<= 51 KB) stay resident in LDS; workgroups are persistent over tiles.
 // With `wav != nullptr` the x tile is computed from the waveform (SEANetEncoder model[0], k=7,
@@ -18,11 +18,12 @@ namespace wt {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-static constexpr int RB_ROWS = 128;   // frames per tile
 
-__device__ __forceinline__ float rb_elu(float x) { return x > 0.f ? x : expm1f(x); }
+// elu(x) = x > 0 ? x : exp(x) - 1 (the form ATen's CPU kernel evaluates); __expf keeps the absolute error at
+// ~1e-7, the size of fp32 rounding of the O(1) activations it feeds
+__device__ __forceinline__ float rb_elu(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
 
-template <int C>
+template <int C, int ROWS>
 struct RbLayout {
     static constexpr int H = C / 2;                 // hidden channels
     static constexpr int N1 = H < 32 ? 32 : H;      // conv3 output columns padded to an MFMA tile
@@ -30,22 +31,21 @@ struct RbLayout {
     static constexpr int PH = H + 4;                // pitch of hidden rows
     static constexpr int K1 = 3 * C, P1 = K1 + 4;   // conv3 weights [N1][P1]
     static constexpr int K2 = H + C, P2 = K2 + 4;   // [conv1 | shortcut] weights [C][P2]
-    static constexpr int NX = RB_ROWS + 2;
+    static constexpr int NX = ROWS + 2;
     static constexpr int off_xr = 0;
-    static constexpr int off_xe = off_xr + NX * PX;
-    static constexpr int off_he = off_xe + NX * PX;
-    static constexpr int off_w1 = off_he + RB_ROWS * PH;
+    static constexpr int off_he = off_xr + NX * PX;
+    static constexpr int off_w1 = off_he + ROWS * PH;
     static constexpr int off_w2 = off_w1 + N1 * P1;
     static constexpr int off_b = off_w2 + C * P2;   // b3[N1], b12[C]
     static constexpr int total = off_b + N1 + C;
 };
 
-template <int C>
-__global__ __launch_bounds__(256) void resblock_kernel(const ResblockArgs a) {
-    using L = RbLayout<C>;
+template <int C, int ROWS>
+__global__ __launch_bounds__(ROWS * 2) void resblock_kernel(const ResblockArgs a) {
+    using L = RbLayout<C, ROWS>;
+    constexpr int NT = ROWS * 2;                     // one wave per 32 frames
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xr = smem + L::off_xr;
-    float* xe = smem + L::off_xe;
     float* he = smem + L::off_he;
     float* w1 = smem + L::off_w1;
     float* w2 = smem + L::off_w2;
@@ -53,23 +53,23 @@ __global__ __launch_bounds__(256) void resblock_kernel(const ResblockArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     // ---- resident weights
-    for (int e = tid; e < L::N1 * (L::K1 / 4); e += 256) {
+    for (int e = tid; e < L::N1 * (L::K1 / 4); e += NT) {
         const int n = e / (L::K1 / 4), k4 = (e - n * (L::K1 / 4)) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (n < L::H) v = *reinterpret_cast<const f32x4*>(a.W3 + (long)n * L::K1 + k4);
         *reinterpret_cast<f32x4*>(w1 + n * L::P1 + k4) = v;
     }
-    for (int e = tid; e < C * (L::K2 / 4); e += 256) {
+    for (int e = tid; e < C * (L::K2 / 4); e += NT) {
         const int n = e / (L::K2 / 4), k4 = (e - n * (L::K2 / 4)) * 4;
         f32x4 v;
         if (k4 < L::H) v = *reinterpret_cast<const f32x4*>(a.W1 + (long)n * L::H + k4);
         else v = *reinterpret_cast<const f32x4*>(a.Ws + (long)n * C + (k4 - L::H));
         *reinterpret_cast<f32x4*>(w2 + n * L::P2 + k4) = v;
     }
-    for (int e = tid; e < L::N1 + C; e += 256)
+    for (int e = tid; e < L::N1 + C; e += NT)
         bb[e] = e < L::N1 ? (e < L::H ? a.b3[e] : 0.f) : (a.b1[e - L::N1] + a.bs[e - L::N1]);
 
-    const int tiles_per_clip = (a.T + RB_ROWS - 1) / RB_ROWS;
+    const int tiles_per_clip = (a.T + ROWS - 1) / ROWS;
     const long n_tiles = (long)a.B * tiles_per_clip;
     const int Tp1 = a.T > 1 ? a.T : 2;               // reflect pad 1 (k=3): conv.py:86-91
     const int Tp3 = a.T > 3 ? a.T : 4;               // reflect pad 3 (k=7)
@@ -79,10 +79,10 @@ __global__ __launch_bounds__(256) void resblock_kernel(const ResblockArgs a) {
 
     for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int b = (int)(tile / tiles_per_clip);
-        const int t0 = (int)(tile - (long)b * tiles_per_clip) * RB_ROWS;
+        const int t0 = (int)(tile - (long)b * tiles_per_clip) * ROWS;
         __syncthreads();                             // previous tile fully consumed (and weights landed)
-        // ---- x tile: frames t0-1 .. t0+128, reflect-resolved; raw and ELU'd copies
-        for (int e = tid; e < L::NX * (C / 4); e += 256) {
+        // ---- x tile: frames t0-1 .. t0+ROWS, reflect-resolved (raw; ELU is applied on the operand read)
+        for (int e = tid; e < L::NX * (C / 4); e += NT) {
             const int r = e / (C / 4), c4 = (e - r * (C / 4)) * 4;
             int pos = t0 - 1 + r;
             pos = pos < 0 ? -pos : pos;
@@ -105,8 +105,6 @@ __global__ __launch_bounds__(256) void resblock_kernel(const ResblockArgs a) {
                 }
             }
             *reinterpret_cast<f32x4*>(xr + r * L::PX + c4) = v;
-            f32x4 u = {rb_elu(v.x), rb_elu(v.y), rb_elu(v.z), rb_elu(v.w)};
-            *reinterpret_cast<f32x4*>(xe + r * L::PX + c4) = u;
         }
         __syncthreads();
 
@@ -121,7 +119,8 @@ __global__ __launch_bounds__(256) void resblock_kernel(const ResblockArgs a) {
         for (int q = 0; q < L::K1 / 8; ++q) {
             const int kk = q * 8 + 4 * lh;
             const int tap = kk / C, ci = kk - tap * C;
-            const f32x4 fa = *reinterpret_cast<const f32x4*>(xe + (row0 + li + tap) * L::PX + ci);
+            f32x4 fa = *reinterpret_cast<const f32x4*>(xr + (row0 + li + tap) * L::PX + ci);
+            fa.x = rb_elu(fa.x); fa.y = rb_elu(fa.y); fa.z = rb_elu(fa.z); fa.w = rb_elu(fa.w);
             f32x4 fb[TN1];
 #pragma unroll
             for (int j = 0; j < TN1; ++j) fb[j] = *reinterpret_cast<const f32x4*>(w1 + (j * 32 + li) * L::P1 + kk);
@@ -182,20 +181,20 @@ __global__ __launch_bounds__(256) void resblock_kernel(const ResblockArgs a) {
     }
 }
 
-template <int C>
+template <int C, int ROWS>
 static int launch_rb(const ResblockArgs& a, hipStream_t s) {
     static bool attr_set = false;
-    constexpr size_t smem = (size_t)RbLayout<C>::total * sizeof(float);
-    auto kern = resblock_kernel<C>;
+    constexpr size_t smem = (size_t)RbLayout<C, ROWS>::total * sizeof(float);
+    auto kern = resblock_kernel<C, ROWS>;
     if (!attr_set) {
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)smem));
         attr_set = true;
     }
-    const long tiles = (long)a.B * ((a.T + RB_ROWS - 1) / RB_ROWS);
-    const int per_cu = smem <= 80 * 1024 ? 2 : 1;
+    const long tiles = (long)a.B * ((a.T + ROWS - 1) / ROWS);
+    const int per_cu = (int)(160 * 1024 / smem) < 4 ? (int)(160 * 1024 / smem) : 4;
     const long grid = tiles < 256L * per_cu ? tiles : 256L * per_cu;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(ROWS * 2), smem, s, a);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -204,8 +203,8 @@ bool resblock_fusable(int C) { return C == 32 || C == 64; }
 
 int launch_resblock(const ResblockArgs& a, hipStream_t s) {
     if (a.wav && a.C != 32) { set_error("resblock: the folded first conv needs C == 32"); return -1; }
-    if (a.C == 32) return launch_rb<32>(a, s);
-    if (a.C == 64) return launch_rb<64>(a, s);
+    if (a.C == 32) return launch_rb<32, 128>(a, s);     // 48 KB LDS: 3 workgroups per CU
+    if (a.C == 64) return launch_rb<64, 64>(a, s);      // 78 KB LDS: 2 workgroups (of 2 waves) per CU
     set_error("resblock: fused kernel exists for C = 32 and 64");
     return -1;
 }
