@@ -33,7 +33,6 @@ enum Epi : int {
     EPI_BIAS_GELU = 2,       // C = gelu_erf(acc + bias[n])
     EPI_BIAS_GAMMA_RES = 3,  // C = R[m][n] + gamma[n] * (acc + bias[n])
     EPI_HEAD = 4,            // ISTFTHead: paired (log-mag, phase) column tiles -> re/im spectrum
-    EPI_OLA = 5,             // ISTFT overlap-add rows -> trimmed waveform / window envelope
     EPI_ARGMAX = 6,          // VQ: per-row argmax of -(xx - 2 acc + ee[n]) over this wave's columns
     EPI_SCALE = 7,           // C = alpha * acc
     EPI_BIAS_ROW = 8,        // C = acc + bias[m]
@@ -68,9 +67,6 @@ struct GemmArgs {
     long zA = 0, zW = 0, zC = 0;
     // EPI_HEAD
     int head_kb = 0;      // padded bins per half; C row = [re (kb) | im (kb)]
-    // EPI_OLA
-    int ola_L = 0, ola_hop = 0, ola_pad = 0, ola_R = 0;
-    const float* ola_wsq = nullptr;   // window^2 [n_fft]
     // EPI_ARGMAX
     const float* vq_xx = nullptr;     // [M] row |x|^2
     const float* vq_ee = nullptr;     // [N] |e|^2
@@ -100,6 +96,8 @@ enum RowNormMode : int { RN_DWCONV = 0, RN_PLAIN = 1, RN_AFFINE_IN = 2 };
 int launch_rownorm(int mode, const float* x, float* y, int B, int L, int C, const float* dw_w /*[7][C]*/,
                    const float* dw_b, const float* in_scale, const float* in_shift, const float* out_scale,
                    const float* out_shift, float eps, hipStream_t s);
+int launch_istft_ola(const float* parts /*[4][M][Kq]*/, const float* win, const float* wsq, float* out, int B, int L,
+                     int n_fft, int hop, int Kq, hipStream_t s);
 int launch_softmax(float* S, int rows, int L, int ld, hipStream_t s);
 int launch_row_sumsq(const float* x, float* out, long rows, int D, hipStream_t s);
 int launch_vq_finalize(const float* pval, const int* pidx, int nparts, const float* embed, int64_t* codes,

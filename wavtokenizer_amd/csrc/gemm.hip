@@ -313,20 +313,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                     Cg[(long)m * p.c_rstride + n] = v * p.alpha;
                 } else if (EPI == EPI_BIAS_ROW) {
                     Cg[(long)m * p.c_rstride + n] = v + p.bias[m];
-                } else if (EPI == EPI_OLA) {
-                    // spectral_ops.py:60-73: frame rows already windowed by the basis; row m is
-                    // hop-aligned block j' of the un-trimmed signal, column n its sample r
-                    const int b = m / p.T_out;
-                    const int jp = m - b * p.T_out;
-                    const long u = (long)p.ola_hop * jp + n - p.ola_pad;
-                    if (u >= 0 && u < (long)p.ola_hop * p.ola_L) {
-                        float env = 0.f;
-                        for (int d = 0; d < p.ola_R; ++d) {
-                            const int tt = jp - d;
-                            if (tt >= 0 && tt < p.ola_L) env += p.ola_wsq[n + p.ola_hop * d];
-                        }
-                        Cg[(long)b * p.ola_hop * p.ola_L + u] = v / env;
-                    }
                 }
             }
         }
@@ -445,7 +431,6 @@ int launch_gemm(const GemmArgs& a_in, int pro, int epi, hipStream_t s) {
     WT_CASE(PRO_NONE, EPI_BIAS_GELU)
     WT_CASE(PRO_NONE, EPI_BIAS_GAMMA_RES)
     WT_CASE(PRO_NONE, EPI_HEAD)
-    WT_CASE(PRO_NONE, EPI_OLA)
     WT_CASE(PRO_NONE, EPI_ARGMAX)
     WT_CASE(PRO_NONE, EPI_SCALE)
     WT_CASE(PRO_NONE, EPI_BIAS_ROW)

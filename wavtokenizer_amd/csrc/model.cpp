@@ -76,8 +76,8 @@ struct wt_model {
     std::vector<wt::CnxBlock> cnx;
     float *fln_w, *fln_b;
     float *head_W = nullptr, *head_b = nullptr;
-    int Kb = 0, bins_f = 0, R = 0;
-    float *istft_W = nullptr, *wsq = nullptr;
+    int Kb = 0, Kq = 0, bins_f = 0, R = 0;
+    float *istft_W = nullptr, *wsq = nullptr, *win = nullptr;
     // SEANetDecoder (present iff the checkpoint holds it)
     bool has_seadec = false;
     wt::ConvW sd_first;
@@ -321,18 +321,25 @@ static int build_model(wt_model* M, TensorMap& tm) {
         if (N % hop != 0 || N % 2 != 0 || (N - hop) % 2 != 0) {
             set_error("ISTFT kernel needs n_fft to be an even multiple of hop_length"); return WT_ERR_INVALID;
         }
+        if (N % 4 != 0) { set_error("ISTFT kernel needs n_fft % 4 == 0"); return WT_ERR_INVALID; }
         const int bins = N / 2 + 1;
-        const int Kb = ((bins + 31) / 32) * 32;
+        const int Q = N / 4;
+        const int Kq = ((Q + 1 + 31) / 32) * 32;          // padded count of even (Q+1) / odd (Q) bins
+        const int Kb = 2 * Kq;                            // spectrum half-row: [even bins | odd bins]
         const int R = N / hop;
-        M->Kb = Kb; M->bins_f = bins; M->R = R;
+        M->Kb = Kb; M->Kq = Kq; M->bins_f = bins; M->R = R;
         const float* w = tm.get("head.out.weight", (int64_t)(N + 2) * D);
         const float* b = tm.get("head.out.bias", N + 2);
         const float* win = tm.get("head.istft.window", N);
         if (!w || !b || !win) return WT_ERR_MISSING_TENSOR;
-        // packed rows: 64-row groups = 32 log-magnitude rows then the 32 phase rows of the same bins
+        // spectrum slot s -> frequency bin: s < Kq: even bin 2s; else odd bin 2(s-Kq)+1 (-1 = padding)
+        auto slot_bin = [&](int s) { int f = s < Kq ? 2 * s : 2 * (s - Kq) + 1; return f <= N / 2 && (s < Kq || s - Kq < Q) ? f : -1; };
+        // packed head rows: 64-row groups = 32 log-magnitude rows then the 32 phase rows of the same slots
         std::vector<float> wp((size_t)2 * Kb * D, 0.f), bp((size_t)2 * Kb, 0.f);
-        for (int f = 0; f < bins; ++f) {
-            const size_t pm = (size_t)(f / 32) * 64 + (f % 32), pp = pm + 32;
+        for (int sl = 0; sl < Kb; ++sl) {
+            const int f = slot_bin(sl);
+            if (f < 0) continue;
+            const size_t pm = (size_t)(sl / 32) * 64 + (sl % 32), pp = pm + 32;
             std::memcpy(&wp[pm * D], &w[(size_t)f * D], D * sizeof(float));
             std::memcpy(&wp[pp * D], &w[(size_t)(bins + f) * D], D * sizeof(float));
             bp[pm] = b[f];
@@ -340,26 +347,29 @@ static int build_model(wt_model* M, TensorMap& tm) {
         }
         if (int rc = upload(M, wp, &M->head_W)) return rc;
         if (int rc = upload(M, bp, &M->head_b)) return rc;
-        // windowed inverse real-DFT basis, one K block per overlapping frame (see gemm.hip EPI_OLA)
-        const size_t Kt = (size_t)R * 2 * Kb;
-        std::vector<float> basis((size_t)hop * Kt, 0.f);
+        // Inverse real DFT, two radix-2 splits then dense: with theta = 2 pi f n / N,
+        //   x[n] = C[n] - S[n], x[N-n] = C[n] + S[n]            (n <= N/2;  C = sum c_f Re cos, S = sum c_f Im sin, /N)
+        //   C[n] = Ce[n] + Co[n], C[N/2-n] = Ce[n] - Co[n]      (n <= N/4;  even / odd bins)
+        //   S[n] = Se[n] + So[n], S[N/2-n] = So[n] - Se[n]
+        // so four (N/4+1) x (N/4+1) bases replace the N x (N/2+1) complex one: 1/4 of the multiply-adds.
+        std::vector<float> basis((size_t)4 * Kq * Kq, 0.f);
         const double two_pi = 6.283185307179586476925286766559;
-        for (int r = 0; r < hop; ++r)
-            for (int tau = 0; tau < R; ++tau) {
-                const int d = R - 1 - tau;
-                const int n = r + hop * d;
-                const double wn = (double)win[n] / (double)N;
-                float* row = &basis[(size_t)r * Kt + (size_t)tau * 2 * Kb];
-                for (int f = 0; f < bins; ++f) {
-                    const bool edge = (f == 0) || (f == N / 2);
-                    const double cf = edge ? 1.0 : 2.0;
-                    const long ph = ((long)f * n) % N;
-                    const double th = two_pi * (double)ph / (double)N;
-                    row[f] = (float)(cf * std::cos(th) * wn);
-                    row[Kb + f] = edge ? 0.f : (float)(-cf * std::sin(th) * wn);   // C2R ignores Im of DC/Nyquist
+        for (int n = 0; n <= Q; ++n)
+            for (int g = 0; g <= Q; ++g) {
+                const int fe = 2 * g, fo = 2 * g + 1;
+                const bool edge = (fe == 0) || (fe == N / 2);
+                const double ce = (edge ? 1.0 : 2.0) / (double)N, co = 2.0 / (double)N;
+                const double the = two_pi * (double)(((long)fe * n) % N) / (double)N;
+                const double tho = two_pi * (double)(((long)fo * n) % N) / (double)N;
+                basis[((size_t)0 * Kq + n) * Kq + g] = (float)(ce * std::cos(the));
+                basis[((size_t)2 * Kq + n) * Kq + g] = edge ? 0.f : (float)(ce * std::sin(the));   // C2R ignores Im of DC/Nyquist
+                if (g < Q) {
+                    basis[((size_t)1 * Kq + n) * Kq + g] = (float)(co * std::cos(tho));
+                    basis[((size_t)3 * Kq + n) * Kq + g] = (float)(co * std::sin(tho));
                 }
             }
         if (int rc = upload(M, basis, &M->istft_W)) return rc;
+        if (int rc = upload_raw(M, win, N, &M->win)) return rc;
         std::vector<float> wsq(N);
         for (int n = 0; n < N; ++n) wsq[n] = win[n] * win[n];
         if (int rc = upload(M, wsq, &M->wsq)) return rc;
@@ -828,24 +838,27 @@ static int build_decode(wt_plan* P) {
         return 0;
     });
     // ISTFTHead (heads.py:53-66): Linear + exp/clip/cos/sin fused -> spectrum rows [re | im]
-    const int Kb = M->Kb, R = M->R, hop = ar.hop_length;
+    const int Kb = M->Kb, hop = ar.hop_length;
     const int spec = P->buf("head.spec", (size_t)Mrows * 2 * Kb);
     GemmArgs ah = linear_args(M->head_W, M->head_b, Mrows, 2 * Kb, D);
     P->step({xo, spec}, [=](const RunCtx& c) {
         GemmArgs a = ah; a.A = P->ptr(c, xo); a.C = P->ptr(c, spec); a.c_rstride = 2 * Kb; a.head_kb = Kb;
         return launch_gemm(a, PRO_NONE, EPI_HEAD, c.stream);
     }, 1, "head.out");
-    // ISTFT (spectral_ops.py:56-73): windowed inverse DFT + overlap-add + trim + envelope divide
-    P->step({spec}, [=](const RunCtx& c) {
-        GemmArgs a;
-        a.A = P->ptr(c, spec); a.a_bstride = (long)L * 2 * Kb; a.a_rstride = 2 * Kb;
-        a.T_in = L; a.T_out = L + R - 1; a.Cin = 2 * Kb; a.taps = R; a.pad_left = R - 1; a.pad_mode = PAD_ZERO;
-        a.W = M->istft_W; a.w_rstride = (long)R * 2 * Kb;
-        a.M = B * (L + R - 1); a.N = hop; a.K = R * 2 * Kb;
-        a.C = c.out_f; a.c_rstride = hop;
-        a.ola_L = L; a.ola_hop = hop; a.ola_pad = (ar.n_fft - hop) / 2; a.ola_R = R; a.ola_wsq = M->wsq;
-        return launch_gemm(a, PRO_NONE, EPI_OLA, c.stream);
+    // ISTFT (spectral_ops.py:56-73): four quarter-size real transforms as one batched GEMM, then the
+    // butterflies + window + overlap-add + trim + envelope divide in one pass
+    const int Kq = M->Kq;
+    const int parts = P->buf("head.parts", (size_t)4 * Mrows * Kq);       // Ce, Co, Se, So: [4][M][Kq]
+    P->step({spec, parts}, [=](const RunCtx& c) {
+        GemmArgs a = linear_args(M->istft_W, nullptr, Mrows, Kq, Kq);
+        a.A = P->ptr(c, spec); a.a_rstride = 2 * Kb; a.zA = Kq;              // z picks the spectrum quarter
+        a.zW = (long)Kq * Kq; a.nz = 4;
+        a.C = P->ptr(c, parts); a.c_rstride = Kq; a.zC = (long)Mrows * Kq;
+        return launch_gemm(a, PRO_NONE, EPI_BIAS, c.stream);
     }, 1, "head.istft");
+    P->step({parts}, [=](const RunCtx& c) {
+        return launch_istft_ola(P->ptr(c, parts), M->win, M->wsq, c.out_f, B, L, ar.n_fft, hop, Kq, c.stream);
+    }, 1, "head.ola");
     return 0;
 }
 

@@ -353,6 +353,54 @@ int launch_softmax(float* S, int rows, int L, int ld, hipStream_t s) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------- ISTFT tail
+// ISTFT.forward 'same' (decoder/spectral_ops.py:56-73) after the four quarter transforms
+// Ce, Co, Se, So [frame][0..N/4]: rebuild x_t[n] with the two radix-2 butterflies, multiply by the
+// window, overlap-add the n_fft/hop frames that cover an output sample (ascending n, like fold),
+// trim (n_fft-hop)/2 and divide by the window-square envelope.  One thread per output sample.
+__global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict__ parts, const float* __restrict__ win,
+                                                        const float* __restrict__ wsq, float* __restrict__ out,
+                                                        long total, long Mrows, int L, int N, int hop, int Kq) {
+    const int pad = (N - hop) / 2, R = N / hop, Q = N / 4, Nh = N / 2;
+    const long Tout = (long)hop * L;
+    const float* Ce = parts;
+    const float* Co = parts + Mrows * Kq;
+    const float* Se = parts + 2 * Mrows * Kq;
+    const float* So = parts + 3 * Mrows * Kq;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long b = idx / Tout;
+        const long u = idx - b * Tout;
+        const long up = u + pad;
+        const int jp = (int)(up / hop), r = (int)(up - (long)jp * hop);
+        float acc = 0.f, env = 0.f;
+        for (int d = 0; d < R; ++d) {
+            const int t = jp - d;
+            if (t < 0 || t >= L) continue;
+            const int n = r + hop * d;
+            const int m = n <= Nh ? n : N - n;               // x[N-m] = C[m] + S[m]
+            const int mm = m <= Q ? m : Nh - m;              // C[N/2-mm] = Ce - Co, S[N/2-mm] = So - Se
+            const long o = (b * L + t) * Kq + mm;
+            const float ce = Ce[o], co = Co[o], se = Se[o], so = So[o];
+            const float Cv = m <= Q ? ce + co : ce - co;
+            const float Sv = m <= Q ? se + so : so - se;
+            const float x = n <= Nh ? Cv - Sv : Cv + Sv;
+            acc += x * win[n];
+            env += wsq[n];
+        }
+        out[idx] = acc / env;
+    }
+}
+
+int launch_istft_ola(const float* parts, const float* win, const float* wsq, float* out, int B, int L, int n_fft, int hop,
+                     int Kq, hipStream_t s) {
+    const long total = (long)B * L * hop;
+    int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(istft_ola_kernel, dim3(blocks), dim3(256), 0, s, parts, win, wsq, out, total, (long)B * L, L, n_fft,
+                       hop, Kq);
+    WT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // ----------------------------------------------------------------------------------------- VQ
 __global__ __launch_bounds__(256) void row_sumsq_kernel(const float* __restrict__ x, float* __restrict__ out, long rows,
                                                         int D) {
