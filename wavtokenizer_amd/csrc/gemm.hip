@@ -362,13 +362,16 @@ static int launch_tiled(const GemmArgs& a, hipStream_t s) {
         if (a.N <= 32) return launch_one<128, 32, 4, 1, PRO, EPI>(a, s);
         if (a.N <= 64) return launch_one<128, 64, 2, 2, PRO, EPI>(a, s);
         {
-            // 512 workgroup slots (2 per CU).  Cost of a tiling ~ rounds of slots x tile width; take
-            // 128x96 tiles when 128x128 would leave most of the chip idle in its last round
-            // (e.g. 7680x768: 360 tiles on 512 slots).  Measured: tools/gemm_bench.py.
+            // 512 workgroup slots (2 per CU).  Cost of a tiling ~ rounds of slots x tile width / tile
+            // efficiency; narrower tiles win when 128x128 would leave most of the chip idle in its last
+            // round (7680x768: 360 tiles on 512 slots; 7680x512: 240).  Measured: tools/gemm_bench.py.
             const long tm = (a.M + 127) / 128;
-            const long t128 = tm * ((a.N + 127) / 128) * a.nz, t96 = tm * ((a.N + 95) / 96) * a.nz;
-            const double c128 = std::ceil((double)t128 / 512.0) * 128.0;
-            const double c96 = std::ceil((double)t96 / 512.0) * 96.0 / 0.97;
+            auto cost = [&](int bn, double eff) {
+                const long t = tm * ((a.N + bn - 1) / bn) * a.nz;
+                return std::ceil((double)t / 512.0) * bn / eff;
+            };
+            const double c128 = cost(128, 1.0), c96 = cost(96, 0.97), c64 = cost(64, 0.88);
+            if (c64 < c96 && c64 < c128) return launch_one<128, 64, 2, 2, PRO, EPI>(a, s);
             if (c96 < c128) return launch_one<128, 96, 4, 1, PRO, EPI>(a, s);
         }
         return launch_one<128, 128, 2, 2, PRO, EPI>(a, s);

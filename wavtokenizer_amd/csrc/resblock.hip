@@ -77,36 +77,86 @@ __global__ __launch_bounds__(ROWS * 2) void resblock_kernel(const ResblockArgs a
     const int li = lane & 31, lh = lane >> 5;
     const int row0 = wave * 32;                      // this wave's frames inside the tile
 
+    // x tile = frames t0-1 .. t0+ROWS (reflect-resolved).  The global loads of tile i+1 are issued before
+    // the contractions of tile i and parked in registers, so their latency hides under the MFMAs.
+    constexpr int XITEMS = (L::NX * (C / 4) + NT - 1) / NT;        // float4 per thread per x tile
+    constexpr int WAVN = ROWS + 8;                                  // waveform samples per tile (k=7 halo + k=3 halo)
+    float* wtile = he;                                              // folded first conv: staged in he (free at this point)
+    f32x4 px[XITEMS];
+    float pw = 0.f;
+    auto prefetch = [&](long tile) {
+        const int b = (int)(tile / tiles_per_clip);
+        const int t0 = (int)(tile - (long)b * tiles_per_clip) * ROWS;
+        if (a.wav) {
+            if (tid < WAVN) {                                       // sample index t0 - 4 + tid, k=7 reflect
+                int p = t0 - 4 + tid;
+                p = p < 0 ? -p : p;
+                p = p >= Tp3 ? 2 * (Tp3 - 1) - p : p;
+                pw = (p >= 0 && p < a.T) ? a.wav[(long)b * a.T + p] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < XITEMS; ++it) {
+                const int e = tid + it * NT;
+                const int r = e / (C / 4), c4 = (e - r * (C / 4)) * 4;
+                int pos = t0 - 1 + r;
+                pos = pos < 0 ? -pos : pos;
+                pos = pos >= Tp1 ? 2 * (Tp1 - 1) - pos : pos;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (e < L::NX * (C / 4) && pos >= 0 && pos < a.T)
+                    v = *reinterpret_cast<const f32x4*>(a.x + ((long)b * a.T + pos) * C + c4);
+                px[it] = v;
+            }
+        }
+    };
+    if ((long)blockIdx.x < n_tiles) prefetch(blockIdx.x);
+
     for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int b = (int)(tile / tiles_per_clip);
         const int t0 = (int)(tile - (long)b * tiles_per_clip) * ROWS;
         __syncthreads();                             // previous tile fully consumed (and weights landed)
-        // ---- x tile: frames t0-1 .. t0+ROWS, reflect-resolved (raw; ELU is applied on the operand read)
-        for (int e = tid; e < L::NX * (C / 4); e += NT) {
-            const int r = e / (C / 4), c4 = (e - r * (C / 4)) * 4;
-            int pos = t0 - 1 + r;
-            pos = pos < 0 ? -pos : pos;
-            pos = pos >= Tp1 ? 2 * (Tp1 - 1) - pos : pos;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (pos >= 0 && pos < a.T) {
-                if (a.wav) {                          // first encoder conv on the fly
+        if (a.wav) {
+            // first encoder conv from the staged samples: x[f] = b + sum_j w[j] * wav[refl(f + j - 3)]
+            if (tid < WAVN) wtile[tid] = pw;
+            __syncthreads();
+            for (int e = tid; e < L::NX * (C / 4); e += NT) {
+                const int r = e / (C / 4), c4 = (e - r * (C / 4)) * 4;
+                int pos = t0 - 1 + r;                // frame of this x row, k=3 reflect
+                pos = pos < 0 ? -pos : pos;
+                pos = pos >= Tp1 ? 2 * (Tp1 - 1) - pos : pos;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (pos >= 0 && pos < a.T) {
                     v = *reinterpret_cast<const f32x4*>(a.e0_b + c4);
-                    const float* w = a.wav + (long)b * a.T;
 #pragma unroll
                     for (int j = 0; j < 7; ++j) {
+                        // the staged window holds raw positions t0-4 .. t0+ROWS+3; a reflected frame near a clip
+                        // edge may need samples outside it, which are re-read from memory (rare)
                         int p = pos + j - 3;
                         p = p < 0 ? -p : p;
                         p = p >= Tp3 ? 2 * (Tp3 - 1) - p : p;
-                        const float xv = p < a.T ? w[p] : 0.f;
+                        float xv = 0.f;
+                        if (p >= 0 && p < a.T) {
+                            const int wi = p - (t0 - 4);
+                            const bool direct = (t0 - 4 >= 0) && (t0 + ROWS + 4 <= a.T);   // window not reflected itself
+                            xv = (direct && wi >= 0 && wi < WAVN) ? wtile[wi] : a.wav[(long)b * a.T + p];
+                        }
                         v += xv * *reinterpret_cast<const f32x4*>(a.e0_w + j * C + c4);
                     }
-                } else {
-                    v = *reinterpret_cast<const f32x4*>(a.x + ((long)b * a.T + pos) * C + c4);
+                }
+                *reinterpret_cast<f32x4*>(xr + r * L::PX + c4) = v;
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < XITEMS; ++it) {
+                const int e = tid + it * NT;
+                if (e < L::NX * (C / 4)) {
+                    const int r = e / (C / 4), c4 = (e - r * (C / 4)) * 4;
+                    *reinterpret_cast<f32x4*>(xr + r * L::PX + c4) = px[it];
                 }
             }
-            *reinterpret_cast<f32x4*>(xr + r * L::PX + c4) = v;
         }
         __syncthreads();
+        if (tile + gridDim.x < n_tiles) prefetch(tile + gridDim.x);
 
         // ---- conv3: h[32 frames][N1] = sum over (tap, ci) elu(x)[frame + tap - 1][ci] * W3[n][tap][ci]
         constexpr int TN1 = L::N1 / 32;
