@@ -36,8 +36,8 @@ CLIP_SECONDS = 3
 SAMPLE_RATE = 24000
 # algorithmic GFLOP per 3 s clip (2*MAC: convs, linears, LSTM, VQ, attention)
 GFLOP_PER_CLIP = {"hop600": 20.852, "hop320": 38.910}
-WORKLOAD = {"hop600": "WavTokenizer-small-600-24k-4096 (40 tok/s), encode_infer+decode round trip, 3 s 24 kHz clips",
-            "hop320": "WavTokenizer-small-320-24k-4096 (75 tok/s), encode_infer+decode round trip, 3 s 24 kHz clips"}
+WORKLOAD = {"hop600": "WavTokenizer-small-600-24k-4096 (40 tok/s), encode_infer+decode round trip, 24 kHz clips",
+            "hop320": "WavTokenizer-small-320-24k-4096 (75 tok/s), encode_infer+decode round trip, 24 kHz clips"}
 
 
 def cpu_baseline(arch_name, sd, clips_np):
@@ -88,7 +88,7 @@ def pmc_traffic(arch_name, B):
     FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected: tools/summarize_profile.py); None if there is
     no summary for this workload.  PMC counters cannot be read from inside the timed process."""
     import glob
-    if arch_name != "hop600" or B != 64:
+    if arch_name != "hop600" or B != 64 or CLIP_SECONDS != 3:
         return None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
@@ -102,12 +102,14 @@ def pmc_traffic(arch_name, B):
 
 
 def main():
+    global CLIP_SECONDS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--arch", default="hop600", choices=["hop600", "hop320"])
     ap.add_argument("--clips", type=int, default=64, help="clips per GPU per step")
+    ap.add_argument("--clip-seconds", type=int, default=3, help="clip length (BASELINE configs[4] uses 30 s clips)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     args = ap.parse_args()
@@ -134,6 +136,7 @@ def main():
     model = WavTokenizer.from_arch(arch)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     model = model.eval().to(dev)
+    CLIP_SECONDS = args.clip_seconds
     B, T = args.clips, CLIP_SECONDS * SAMPLE_RATE
     clips_np = synth.make_clips(B, T, seed=1000 * 2 + rank)       # seed = 1000*config + index
     wav = torch.from_numpy(clips_np).to(dev)
@@ -182,14 +185,17 @@ def main():
         flops = 2.0 * Mrows * arch.intermediate_dim * arch.dim
         kern_ms = tot_ms.value / max(1, n_l.value)
         achieved = flops / (kern_ms * 1e-3) / 1e12
-        e2e_tflops = GFLOP_PER_CLIP[args.arch] * B * 1e9 / (ms_per_step * 1e-3) / 1e12
+        # SURVEY 8(d) FLOPs are for 3 s clips; attention grows with L^2 (4*L^2*768 per clip)
+        gflop_clip = GFLOP_PER_CLIP[args.arch] * CLIP_SECONDS / 3.0 + 4.0 * arch.dim * (L * L - (L * 3 // CLIP_SECONDS) ** 2 * CLIP_SECONDS / 3.0) / 1e9
+        e2e_tflops = gflop_clip * B * 1e9 / (ms_per_step * 1e-3) / 1e12
         line = {
-            "metric": "audio-seconds/sec encode+decode, 24 kHz 3 s clips",
+            "metric": "audio-seconds/sec encode+decode, 24 kHz %d s clips" % CLIP_SECONDS,
             "value": round(value, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOAD[args.arch], "arch": args.arch, "clips_per_gpu": B,
                        "global_clips": world * B, "clip_seconds": CLIP_SECONDS, "frames_per_clip": L,
+                       "codes_per_sec": round(world * B * L * args.steps / elapsed, 1),
                        "weights": "random-init (synth seed 0)", "parallelism": f"clips sharded dp{world}",
                        "gather": "codes all_gather + waveform gather to rank 0 (RCCL) inside the step" if world > 1 and not args.no_gather else "none"},
             "roofline": {"bound": "mfma", "kernel": "wt::gemm_kernel<128,%d,..,PRO_NONE=0,EPI_BIAS_GELU=2> (ConvNeXt pwconv1 GEMM %dx%dx%d)" % (96 if args.arch == "hop600" and B == 64 else 128, Mrows, arch.intermediate_dim, arch.dim),
