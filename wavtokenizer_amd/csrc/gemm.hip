@@ -124,51 +124,63 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         w_off[i] = n < p.N ? (unsigned)((long)n * p.w_rstride * 4) + (unsigned)kq4 * 4u : OOB;
     }
     __syncthreads();
+    const int nk_ = (p.K + BK - 1) / BK;
 
-    f32x4 ra[NA], rb[NB];
-    int ld_idx[NA];                   // affine prologue: index of (clip, channel), or -1 for padding
-
-    auto load_tile = [&](int k0, int tap, int ci0) {
+    // ---- 3-stage software pipeline over K: while the MFMAs of tile kt run from one LDS buffer, tile
+    //      kt+1 (already in registers, loaded one iteration earlier) is written to the other LDS buffer
+    //      in the MIDDLE of the MFMA block, and the global loads of tile kt+2 are in flight.  Two named
+    //      register sets alternate (the loop is unrolled by two so every index is static).
+    struct Stage { f32x4 a[NA]; f32x4 b[NB]; int idx[NA]; };
+    Stage st0, st1;
+    unsigned a_off[NA];               // row offsets of the tap being loaded (registers; refreshed on a tap change)
+    auto set_tap = [&](int tap) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) a_off[i] = s_rowoff[tap * BM + srow + 32 * i];
+    };
+    int tapL = 0, ciL = 0, kL = 0;    // coordinates of the next tile to load; taps == 1 or Cin % 32 == 0 (host)
+    auto load_tile = [&](Stage& st) {
         // K tail (only K = 16 has one): the OR keeps the offset >= 2^31 whatever is added
-        const unsigned kmask = (k0 + kq4 < p.K) ? 0u : OOB;
-        const unsigned kadv = (unsigned)(ci0 + kq4) * 4u;
+        const unsigned kmask = (kL + kq4 < p.K) ? 0u : OOB;
+        const unsigned kadv = (unsigned)(ciL + kq4) * 4u;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const unsigned ro = s_rowoff[tap * BM + srow + 32 * i];
+            const unsigned ro = a_off[i];
             const unsigned off = (ro | kmask) + kadv;
-            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, 0, 0));
+            st.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, 0, 0));
             if (PRO == PRO_AFFINE || PRO == PRO_AFFINE_SWISH)
-                ld_idx[i] = (a_clipc[i] + ci0 + kq4) | (int)((ro | kmask) & OOB ? -1 : 0);
+                st.idx[i] = (a_clipc[i] + ciL + kq4) | (int)((ro | kmask) & OOB ? -1 : 0);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const unsigned off = (w_off[i] | kmask) + (unsigned)k0 * 4u;
-            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)off, 0, 0));
+            const unsigned off = (w_off[i] | kmask) + (unsigned)kL * 4u;
+            st.b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)off, 0, 0));
         }
+        kL += BK; ciL += BK;
+        if (p.taps > 1 && ciL >= p.Cin && kL < p.K) { ciL = 0; ++tapL; set_tap(tapL); }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](const Stage& st, int buf) {
         float* as = As + buf * BM * LDS_PITCH;
         float* bs = Bs + buf * BN * LDS_PITCH;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            f32x4 v = ra[i];
+            f32x4 v = st.a[i];
             if (PRO == PRO_ELU) {                                  // elu(0) = 0: padding stays 0
                 v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w);
             } else if (PRO == PRO_AFFINE || PRO == PRO_AFFINE_SWISH) {
-                const int idx = ld_idx[i] < 0 ? 0 : ld_idx[i];
+                const int idx = st.idx[i] < 0 ? 0 : st.idx[i];
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(p.pro_scale + idx);
                 const f32x4 sh = *reinterpret_cast<const f32x4*>(p.pro_shift + idx);
                 v = v * sc + sh;
                 if (PRO == PRO_AFFINE_SWISH) {
                     v.x = swish(v.x); v.y = swish(v.y); v.z = swish(v.z); v.w = swish(v.w);
                 }
-                if (ld_idx[i] < 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};   // padding is zero AFTER the norm
+                if (st.idx[i] < 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};   // padding is zero AFTER the norm
             }
             *reinterpret_cast<f32x4*>(as + (srow + 32 * i) * LDS_PITCH + kq4) = v;
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i)
-            *reinterpret_cast<f32x4*>(bs + (srow + 32 * i) * LDS_PITCH + kq4) = rb[i];
+            *reinterpret_cast<f32x4*>(bs + (srow + 32 * i) * LDS_PITCH + kq4) = st.b[i];
     };
 
     f32x16 acc[TM][TN];
@@ -179,41 +191,48 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (p.K + BK - 1) / BK;
-    // (tap, ci0) of the K step being loaded; host guarantees taps == 1 or Cin % 32 == 0
-    int tap = 0, ci0 = 0;
-    load_tile(0, 0, 0);
-    store_tile(0);
-    __syncthreads();
-
     const int frag_off = (lane & 31) * LDS_PITCH + 4 * (lane >> 5);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) {
-            ci0 += BK;
-            if (p.taps > 1 && ci0 >= p.Cin) { ci0 = 0; ++tap; }
-            load_tile((kt + 1) * BK, tap, ci0);
-        }
+    auto mfma_q = [&](int buf, int q) {
         const float* as = As + buf * BM * LDS_PITCH + (wm * WM) * LDS_PITCH + frag_off;
         const float* bs = Bs + buf * BN * LDS_PITCH + (wn * WN) * LDS_PITCH + frag_off;
+        f32x4 fa[TM], fb[TN];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 fa[TM], fb[TN];
+        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDS_PITCH + q * 8);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDS_PITCH + q * 8);
+        for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LDS_PITCH + q * 8);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LDS_PITCH + q * 8);
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+    };
+    // one K step: tile kt is in LDS buffer `buf`, tile kt+1 in `nxt`, tile kt+2 is fetched into `far`
+    // Loads and LDS writes are unconditional: past the end of K the offsets are out of range (zeros come
+    // back, nothing is fetched) and the written buffer is never read.  A conditional load would make hipcc
+    // wait for vmcnt(0) at the LDS write (it merges the two paths' counters), i.e. for the loads just issued.
+    auto k_step = [&](int buf, Stage& nxt, Stage& far) {
+        load_tile(far);
+        mfma_q(buf, 0);
+        mfma_q(buf, 1);
+        store_tile(nxt, buf ^ 1);
+        mfma_q(buf, 2);
+        mfma_q(buf, 3);
         __syncthreads();
+    };
+
+    set_tap(0);
+    load_tile(st0);                       // tile 0
+    store_tile(st0, 0);
+    load_tile(st1);                       // tile 1
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk_; kt += 2) {
+        k_step(0, st1, st0);              // even tile: next is in st1, tile kt+2 goes to st0
+        k_step(1, st0, st1);
     }
+    if (kt < nk_) k_step(0, st1, st0);    // odd tail
 
     // ------------------------------------------------------------------------- epilogue
     const int col_l = lane & 31;
