@@ -203,6 +203,23 @@ def main():
             entry["cases"]["b1_t720000"] = {"clip_seed": seed, "min_margin": m, "B": 1, "T": 720000}
             print(name, "b1_t720000 seed", seed, "min margin", m)
 
+        # -- case F (secondary path A24): SEANetDecoder reached as feature_extractor.encodec.decoder(z)
+        if name == "hop600":
+            sd_dec = synth.make_state_dict(arch, seed=WEIGHT_SEED, with_seanet_decoder=True)
+            ref_d = build_reference(YAMLS[name], sd_dec)
+            orc_d = OracleWavTokenizer(arch, sd_dec)
+            zs = synth.normal("seanet_dec_z", (2, 512, 20), 0.6, 77)
+            with torch.inference_mode():
+                want = ref_d.feature_extractor.encodec.decoder(torch.from_numpy(zs))
+                got = orc_d.seanet_decoder(torch.from_numpy(zs))
+            check_identical("seanet_decoder", got, want)
+            dec_keys = {k: v for k, v in synth.weights_manifest(sd_dec).items() if k not in entry["weights"]}
+            np.savez_compressed(os.path.join(HERE, f"{name}_seanet_decoder.npz"), z=zs, wav_out=want.numpy())
+            entry["cases"]["seanet_decoder"] = {"B": 2, "L": 20, "z_seed": 77}
+            entry["weights_seanet_decoder"] = dec_keys
+            print(name, "seanet_decoder ok", tuple(want.shape))
+            del ref_d, orc_d, sd_dec
+
         # -- case E: B=8 x 3 s from synth seed (inputs regenerated, pinned by SHA), codes + checksums
         wav = synth.make_clips(8, 72000, 5000)
         res = run_case(ref, orc, arch, wav)

@@ -286,13 +286,17 @@ def test_vq_nearest_kernel_and_ties():
 
 
 def test_seanet_decoder():
-    """Secondary path: feature_extractor.encodec.decoder(features) (seanet.py:147-238)."""
+    """Secondary path: feature_extractor.encodec.decoder(features) (seanet.py:147-238) against the
+    reference's captured output, and against the oracle on a second input."""
     m, sd = _model("hop600", with_seanet_decoder=True)
+    g = load_case("hop600", "seanet_decoder")
+    got = m.feature_extractor.encodec.decoder(torch.from_numpy(g["z"]).cuda())
+    assert tuple(got.shape) == g["wav_out"].shape == (2, 1, 20 * 600)
+    assert rel_l2(got.cpu().numpy(), g["wav_out"]) < WAV_REL_TOL
     orc = _oracle("hop600", sd)
     gen = torch.Generator().manual_seed(5)
-    z = torch.randn(2, 512, 20, generator=gen) * 0.6
+    z = torch.randn(3, 512, 33, generator=gen) * 0.6
     with torch.inference_mode():
         want = orc.seanet_decoder(z)
     got = m.feature_extractor.encodec.decoder(z.cuda())
-    assert tuple(got.shape) == tuple(want.shape) == (2, 1, 20 * 600)
     assert rel_l2(got.cpu().numpy(), want.numpy()) < WAV_REL_TOL

@@ -121,3 +121,73 @@ def test_sharded_roundtrip_world2_gloo(n_clips):
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res), res
     assert all(shape == (1, n_clips, 5) for _, _, shape in res)
+
+
+def _fake_lightning_ckpt(path, arch_name, scale=1.0):
+    """A Lightning-style checkpoint: {'state_dict': {...}} with discriminator keys the loader must drop
+    (decoder/pretrained.py:101-105)."""
+    from wavtokenizer_amd.state_spec import full_state_spec
+    from wavtokenizer_amd.config import NAMED_ARCHS
+    g = torch.Generator().manual_seed(3)
+    sd = {k: torch.randn(shape, generator=g) * 0.01 * scale for k, shape in full_state_spec(NAMED_ARCHS[arch_name]).items()}
+    sd["feature_extractor.encodec.quantizer.vq.layers.0._codebook.inited"] = torch.ones(1)
+    sd["multiperioddisc.discriminators.0.convs.0.weight"] = torch.zeros(4, 1, 5, 1)
+    sd["melspec_loss.mel_spec.spectrogram.window"] = torch.zeros(16)
+    torch.save({"state_dict": sd, "epoch": 3, "global_step": 10}, path)
+    return sd
+
+
+def _yaml_for(arch_name, tmp_path):
+    import yaml
+    from wavtokenizer_amd.config import NAMED_ARCHS
+    arch = NAMED_ARCHS[arch_name]
+    cfg = {"model": {"class_path": "decoder.experiment.WavTokenizer", "init_args": {
+        "sample_rate": 24000,
+        "feature_extractor": {"class_path": "decoder.feature_extractors.EncodecFeatures",
+                              "init_args": {"encodec_model": "encodec_24khz", "bandwidths": [6.6, 6.6, 6.6, 6.6],
+                                            "train_codebooks": True, "num_quantizers": 1,
+                                            "dowmsamples": list(arch.ratios), "vq_bins": 4096, "vq_kmeans": 200}},
+        "backbone": {"class_path": "decoder.models.VocosBackbone",
+                     "init_args": {"input_channels": 512, "dim": 768, "intermediate_dim": 2304, "num_layers": 12,
+                                   "adanorm_num_embeddings": 4}},
+        "head": {"class_path": "decoder.heads.ISTFTHead",
+                 "init_args": {"dim": 768, "n_fft": arch.n_fft, "hop_length": arch.hop_length, "padding": "same"}}}}}
+    p = tmp_path / "cfg.yaml"
+    p.write_text(yaml.safe_dump(cfg))
+    return str(p)
+
+
+def test_from_pretrained0802_filters_and_loads(tmp_path):
+    from wavtokenizer_amd import WavTokenizer
+    cfg = _yaml_for("hop320", tmp_path)
+    ck = tmp_path / "m.ckpt"
+    sd = _fake_lightning_ckpt(str(ck), "hop320")
+    m = WavTokenizer.from_pretrained0802(cfg, str(ck))
+    assert not m.training and m.arch.hop == 320
+    got = m.state_dict()
+    assert len(got) == 289 and not any(k.startswith("multiperioddisc") for k in got)
+    for k in ("backbone.convnext.3.pwconv1.weight", "feature_extractor.encodec.encoder.model.3.conv.conv.weight_v", "head.out.bias"):
+        assert torch.equal(got[k], sd[k])
+    # a checkpoint with a missing key is refused like the reference's strict load_state_dict
+    sd2 = {k: v for k, v in sd.items() if k != "head.out.bias"}
+    torch.save({"state_dict": sd2}, str(ck))
+    with pytest.raises(RuntimeError, match="Missing key"):
+        WavTokenizer.from_pretrained0802(cfg, str(ck))
+
+
+def test_from_pretrained0911_averages_best_three(tmp_path):
+    """pretrained.py:117-156: mean of the three `vocos_*` checkpoints with the smallest val-loss suffix."""
+    from wavtokenizer_amd import WavTokenizer
+    cfg = _yaml_for("hop600", tmp_path)
+    folder = tmp_path / "ckpts"
+    folder.mkdir()
+    losses = {"vocos_checkpoint_epoch=1_step=1_val_loss=5.1000.ckpt": 1.0, "vocos_checkpoint_epoch=2_step=2_val_loss=4.9000.ckpt": 2.0,
+              "vocos_checkpoint_epoch=3_step=3_val_loss=5.0000.ckpt": 3.0, "vocos_checkpoint_epoch=4_step=4_val_loss=6.0000.ckpt": 100.0,
+              "last.ckpt": 50.0}
+    sds = {n: _fake_lightning_ckpt(str(folder / n), "hop600", scale=s) for n, s in losses.items()}
+    m = WavTokenizer.from_pretrained0911(cfg, str(folder))
+    key = "backbone.embed.bias"
+    best = sorted(n for n in losses if n.startswith("vocos_"))          # names sort by their val-loss suffix here
+    picked = sorted((n for n in losses if n.startswith("vocos_")), key=lambda n: n[-11:-5])[:3]
+    want = sum(sds[n][key] for n in picked) / 3
+    assert torch.allclose(m.state_dict()[key], want, rtol=1e-6, atol=1e-9), (best, picked)

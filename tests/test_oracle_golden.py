@@ -102,3 +102,20 @@ def test_hann_envelope_same_padding():
     assert env.shape[0] == T * hop
     assert abs(float(env[env.shape[0] // 2]) - 1.5) < 1e-5
     assert float(env.min()) > 0.7
+
+
+def test_seanet_decoder_fixture():
+    """Secondary path: oracle.seanet_decoder against the reference's
+    feature_extractor.encodec.decoder output captured by make_golden.py."""
+    from wavtokenizer_amd import synth
+    m = manifest()
+    sd = synth.make_state_dict(NAMED_ARCHS["hop600"], seed=m["weight_seed"], with_seanet_decoder=True)
+    want_hash = m["archs"]["hop600"]["weights_seanet_decoder"]
+    got_hash = synth.weights_manifest(sd)
+    assert all(got_hash[k]["sha256"] == v["sha256"] for k, v in want_hash.items())
+    g = load_case("hop600", "seanet_decoder")
+    orc = OracleWavTokenizer(NAMED_ARCHS["hop600"], sd)
+    with torch.inference_mode():
+        out = orc.seanet_decoder(torch.from_numpy(g["z"]))
+    assert tuple(out.shape) == g["wav_out"].shape == (2, 1, 20 * 600)
+    assert rel_l2(out.numpy(), g["wav_out"]) < FLOAT_TOL
