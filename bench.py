@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--clip-seconds", type=int, default=3, help="clip length (BASELINE configs[4] uses 30 s clips)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the measured path); gloo only rehearses the N>1 flow on a box with "
+                         "fewer GPUs than ranks (ranks share GPUs, collectives go through host memory)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -122,13 +125,19 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > ndev:
+        raise SystemExit(f"{world} ranks but {ndev} GPUs: RCCL needs one GPU per rank (use --backend gloo to rehearse)")
+    dev = torch.device("cuda", local_rank % max(1, ndev))
+    torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from wavtokenizer_amd import WavTokenizer, NAMED_ARCHS, synth, _capi
     arch = NAMED_ARCHS[args.arch]
@@ -149,11 +158,14 @@ def main():
         feats, codes = model.encode_infer(wav, bandwidth_id=bw)
         out = model.decode(feats, bandwidth_id=bw)
         if world > 1 and not args.no_gather:
+            if args.backend == "gloo":                               # rehearsal only: through host memory
+                codes, out = codes.cpu(), out.cpu()
             codes = gather_codes(codes, dist, world)                 # 8*L bytes per clip, to every rank
             out = gather_waveforms(out, dist, world, rank, dst=0)    # waveforms to rank 0
         return codes, out
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -174,7 +186,7 @@ def main():
     _capi.check(_capi.lib.wt_plan_read_timing(dplan, ctypes.byref(tot_ms), ctypes.byref(n_l), 1), "wt_plan_read_timing")
     _capi.lib.wt_plan_set_timing(dplan, b"")
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -197,7 +209,7 @@ def main():
                        "global_clips": world * B, "clip_seconds": CLIP_SECONDS, "frames_per_clip": L,
                        "codes_per_sec": round(world * B * L * args.steps / elapsed, 1),
                        "weights": "random-init (synth seed 0)", "parallelism": f"clips sharded dp{world}",
-                       "gather": "codes all_gather + waveform gather to rank 0 (RCCL) inside the step" if world > 1 and not args.no_gather else "none"},
+                       "gather": ("codes all_gather + waveform gather to rank 0 (%s) inside the step" % ("RCCL" if args.backend == "nccl" else "gloo rehearsal")) if world > 1 and not args.no_gather else "none"},
             "roofline": {"bound": "mfma", "kernel": "wt::gemm_kernel<128,%d,..,PRO_NONE=0,EPI_BIAS_GELU=2> (ConvNeXt pwconv1 GEMM %dx%dx%d)" % (96 if args.arch == "hop600" and B == 64 else 128, Mrows, arch.intermediate_dim, arch.dim),
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(args.arch, B),
