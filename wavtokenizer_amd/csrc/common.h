@@ -85,7 +85,7 @@ int gemm_init();            // raises dynamic-LDS limits; call once per process/
 int launch_conv_first(const float* wav, const float* w /*[7][Cout]*/, const float* bias, float* y, int B, long T,
                       int k, int Cout, hipStream_t s);
 int launch_conv_last(const float* x /*[B][T][Cin]*/, const float* w /*[k][Cin]*/, const float* bias, float* y /*[B][T]*/,
-                     int B, long T, int Cin, int k, hipStream_t s);
+                     int B, long T, int Cin, int k, int elu_in, hipStream_t s);
 int launch_transpose(const float* in, float* out, int B, int R, int C, hipStream_t s);  // [B][R][C] -> [B][C][R]
 int launch_gn_stats(const float* x, const float* gamma, const float* beta, float* scale, float* shift, int B, int L,
                     int C, int groups, float eps, hipStream_t s);
@@ -132,6 +132,7 @@ struct ResblockArgs {
     const float* bs;
     float* y;             // [B][T][C]
     int B, T, C;
+    long x_bstride;       // elements between clips of x (0 = T*C); x may be a trimmed view of a longer buffer
     int elu_out;          // store elu(y) (the only consumer is ELU -> down conv)
 };
 bool resblock_fusable(int C);

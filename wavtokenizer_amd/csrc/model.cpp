@@ -46,6 +46,7 @@ struct CnxBlock {
 };
 struct SeaDecStage {
     float* tr_w = nullptr;  // [k][cin][cout]
+    float* tr_wp = nullptr; // [stride phases][cout][2 taps][cin]: tap 0 <-> frame t-1 (kernel index r+stride), tap 1 <-> frame t (index r)
     float* tr_b = nullptr;
     int cin = 0, cout = 0, k = 0, r = 0;
     ConvW c3, c1, sc;
@@ -398,6 +399,16 @@ static int build_model(wt_model* M, TensorMap& tm) {
                     for (int j = 0; j < st.k; ++j)
                         pk[((size_t)j * st.cin + ci) * st.cout + co] = w[((size_t)ci * st.cout + co) * st.k + j];
             if (int rc = upload(M, pk, &st.tr_w)) return rc;
+            if (st.k == 2 * r) {      // every output sample has exactly two contributing frames -> one GEMM per phase
+                std::vector<float> pp((size_t)r * st.cout * 2 * st.cin);
+                for (int ph = 0; ph < r; ++ph)
+                    for (int co = 0; co < st.cout; ++co)
+                        for (int ci = 0; ci < st.cin; ++ci) {
+                            pp[(((size_t)ph * st.cout + co) * 2 + 0) * st.cin + ci] = w[((size_t)ci * st.cout + co) * st.k + ph + r];
+                            pp[(((size_t)ph * st.cout + co) * 2 + 1) * st.cin + ci] = w[((size_t)ci * st.cout + co) * st.k + ph];
+                        }
+                if (int rc = upload(M, pp, &st.tr_wp)) return rc;
+            }
             if (int rc = upload_raw(M, b, st.cout, &st.tr_b)) return rc;
             const std::string rp = std::string(DEC) + std::to_string(di + 2);
             const int h = st.cout;
@@ -559,14 +570,16 @@ static GemmArgs linear_args(const float* W, const float* bias, long M, int N, in
 
 // SEANetResnetBlock (seanet.py:62-63): y = shortcut(x) + conv1(elu(conv3(elu(x)))); returns y's buffer
 static int plan_resblock(wt_plan* P, const ConvW& c3, const ConvW& c1, const ConvW& sc, int B, long T, int xin,
-                         const std::string& name, bool elu_out = false, const wt_model* e0 = nullptr) {
+                         const std::string& name, bool elu_out = false, const wt_model* e0 = nullptr, long x_off = 0,
+                         long x_bstride = 0) {
     const int C = sc.cout;
     if (resblock_fusable(C) && !(P->flags & WT_PLAN_FLAG_KEEP_STAGES)) {
         // one fused kernel (resblock.hip); with e0 set, xin is unused and the tile is built from the waveform
         const int y = P->buf(name, (size_t)B * T * C);
         P->step({e0 ? -1 : xin, y}, [=](const RunCtx& c) {
             ResblockArgs a{};
-            a.x = e0 ? nullptr : P->ptr(c, xin);
+            a.x = e0 ? nullptr : P->ptr(c, xin) + x_off;
+            a.x_bstride = x_bstride;
             a.wav = e0 ? c.in_f : nullptr;
             a.e0_w = e0 ? e0->e0_w : nullptr; a.e0_b = e0 ? e0->e0_b : nullptr;
             a.W3 = c3.w; a.b3 = c3.b; a.W1 = c1.w; a.b1 = c1.b; a.Ws = sc.w; a.bs = sc.b;
@@ -579,12 +592,14 @@ static int plan_resblock(wt_plan* P, const ConvW& c3, const ConvW& c1, const Con
     const int y = P->buf(name, (size_t)B * T * C);
     GemmArgs a3 = sconv_args(c3, B, T, 1, 1);
     P->step({xin, h}, [=](const RunCtx& c) {
-        GemmArgs a = a3; a.A = P->ptr(c, xin); a.C = P->ptr(c, h);
+        GemmArgs a = a3; a.A = P->ptr(c, xin) + x_off; a.C = P->ptr(c, h);
+        if (x_bstride) a.a_bstride = x_bstride;
         return launch_gemm(a, PRO_ELU, EPI_BIAS, c.stream);
     });
     GemmArgs as = sconv_args(sc, B, T, 1, 1);
     P->step({xin, y}, [=](const RunCtx& c) {
-        GemmArgs a = as; a.A = P->ptr(c, xin); a.C = P->ptr(c, y);
+        GemmArgs a = as; a.A = P->ptr(c, xin) + x_off; a.C = P->ptr(c, y);
+        if (x_bstride) a.a_bstride = x_bstride;
         return launch_gemm(a, PRO_NONE, EPI_BIAS, c.stream);
     });
     GemmArgs a1 = sconv_args(c1, B, T, 1, 1);
@@ -877,25 +892,50 @@ static int build_seanet_decoder(wt_plan* P) {
             return launch_gemm(a, PRO_NONE, EPI_BIAS, c.stream);
         });
     }
-    x = plan_lstm(P, M->sd_lstm, B, L, H, x, "sdec.1");
+    const bool fuse_elu = !(P->flags & WT_PLAN_FLAG_KEEP_STAGES);      // producers store elu(.) for "ELU -> conv" consumers
+    x = plan_lstm(P, M->sd_lstm, B, L, H, x, "sdec.1", fuse_elu);
     long Tc = L;
     int di = 2;
-    for (const SeaDecStage& st : M->sd_stages) {
+    for (size_t si = 0; si < M->sd_stages.size(); ++si) {
+        const SeaDecStage st = M->sd_stages[si];
         const long To = Tc * st.r;
-        const int y = P->buf("sdec." + std::to_string(di + 1), (size_t)B * To * st.cout);
         const int xin = x;
         const int Tin = (int)Tc;
-        P->step({xin, y}, [=](const RunCtx& c) {
-            return launch_convtr(P->ptr(c, xin), st.tr_w, st.tr_b, P->ptr(c, y), B, Tin, st.cin, st.cout, st.k, st.r, 1, c.stream);
-        });
-        x = plan_resblock(P, st.c3, st.c1, st.sc, B, To, y, "sdec." + std::to_string(di + 2));
+        int y;
+        long y_off = 0, y_bs = 0;
+        if (st.tr_wp) {
+            // SConvTranspose1d (conv.py:232-253) with k = 2*stride: output sample u' = t*stride + r gets
+            // x[t].W[r] + x[t-1].W[r+stride], i.e. per phase r one GEMM over rows t = 0..Tin with the two
+            // frames as K (zero beyond the clip); the phases are the batch dimension and interleave in the
+            // untrimmed output, of which the following resblock reads the trimmed view.
+            const int trim_l = (st.k - st.r) - (st.k - st.r) / 2;
+            y = P->buf("sdec." + std::to_string(di + 1), (size_t)B * (Tin + 1) * st.r * st.cout);
+            y_off = (long)trim_l * st.cout;
+            y_bs = (long)(Tin + 1) * st.r * st.cout;
+            P->step({xin, y}, [=](const RunCtx& c) {
+                GemmArgs a;
+                a.A = P->ptr(c, xin); a.a_bstride = (long)Tin * st.cin; a.a_rstride = st.cin;
+                a.T_in = Tin; a.T_out = Tin + 1; a.Cin = st.cin; a.taps = 2; a.pad_left = 1; a.pad_mode = PAD_ZERO;
+                a.W = st.tr_wp; a.w_rstride = 2L * st.cin; a.zW = (long)st.cout * 2 * st.cin; a.bias = st.tr_b;
+                a.M = B * (Tin + 1); a.N = st.cout; a.K = 2 * st.cin;
+                a.C = P->ptr(c, y); a.c_rstride = (long)st.r * st.cout; a.zC = st.cout; a.nz = st.r;
+                return launch_gemm(a, fuse_elu ? PRO_NONE : PRO_ELU, EPI_BIAS, c.stream);
+            }, 1, "sdec.convtr");
+        } else {
+            y = P->buf("sdec." + std::to_string(di + 1), (size_t)B * To * st.cout);
+            P->step({xin, y}, [=](const RunCtx& c) {
+                return launch_convtr(P->ptr(c, xin), st.tr_w, st.tr_b, P->ptr(c, y), B, Tin, st.cin, st.cout, st.k, st.r,
+                                     fuse_elu ? 0 : 1, c.stream);
+            }, 1, "sdec.convtr");
+        }
+        x = plan_resblock(P, st.c3, st.c1, st.sc, B, To, y, "sdec." + std::to_string(di + 2), fuse_elu, nullptr, y_off, y_bs);
         Tc = To; di += 3;
     }
     const int xin = x;
     const long Tf = Tc;
     P->step({xin}, [=](const RunCtx& c) {
-        return launch_conv_last(P->ptr(c, xin), M->sd_last_w, M->sd_last_b, c.out_f, B, Tf, 32, 7, c.stream);
-    });
+        return launch_conv_last(P->ptr(c, xin), M->sd_last_w, M->sd_last_b, c.out_f, B, Tf, 32, 7, fuse_elu ? 0 : 1, c.stream);
+    }, 1, "sdec.last");
     return 0;
 }
 

@@ -69,39 +69,49 @@ int launch_conv_first(const float* wav, const float* w, const float* bias, float
 // SEANetDecoder final SConv1d(32, 1, k=7) (seanet.py:223-226) with ELU on its input (:222).
 __global__ __launch_bounds__(256) void conv_last_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y,
-                                                        long BT, int T, int Cin, int k, int Tp) {
+                                                        long BT, int T, int Cin, int k, int Tp, int elu_in) {
+    // Cin/4 lanes share one output sample (each owns 4 channels: 16-byte loads, a wave instruction reads
+    // whole 128-byte frame rows back to back); the lanes' partial sums meet in a shuffle reduction.
+    const int lps = Cin >> 2;                       // lanes per sample (8 for the 32-channel last conv)
+    const int sps = 256 / lps;                      // samples per workgroup pass
+    const int sub = threadIdx.x % lps, sl = threadIdx.x / lps;
     const int pl = (k - 1) - (k - 1) / 2;
-    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < BT; m += (long)gridDim.x * blockDim.x) {
-        const long b = m / T;
-        const int t = (int)(m - b * T);
-        float acc = bias[0];
-        for (int j = 0; j < k; ++j) {
-            bool ok;
-            const int pos = reflect_pos(t + j - pl, T, Tp, ok);
-            if (!ok) continue;
-            const float* xr = x + (b * T + pos) * Cin;
-            for (int c = 0; c < Cin; c += 4) {
-                f32x4 xv = *reinterpret_cast<const f32x4*>(xr + c);
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(w + j * Cin + c);
-                xv.x = xv.x > 0.f ? xv.x : expm1f(xv.x);
-                xv.y = xv.y > 0.f ? xv.y : expm1f(xv.y);
-                xv.z = xv.z > 0.f ? xv.z : expm1f(xv.z);
-                xv.w = xv.w > 0.f ? xv.w : expm1f(xv.w);
-                acc += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+    for (long m0 = (long)blockIdx.x * sps; m0 < BT; m0 += (long)gridDim.x * sps) {
+        const long m = m0 + sl;
+        float acc = 0.f;
+        if (m < BT) {
+            const long b = m / T;
+            const int t = (int)(m - b * T);
+            for (int j = 0; j < k; ++j) {
+                bool ok;
+                const int pos = reflect_pos(t + j - pl, T, Tp, ok);
+                if (!ok) continue;
+                f32x4 xv = *reinterpret_cast<const f32x4*>(x + (b * T + pos) * Cin + sub * 4);
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w + j * Cin + sub * 4);
+                if (elu_in) {
+                    xv.x = xv.x > 0.f ? xv.x : __expf(xv.x) - 1.f;
+                    xv.y = xv.y > 0.f ? xv.y : __expf(xv.y) - 1.f;
+                    xv.z = xv.z > 0.f ? xv.z : __expf(xv.z) - 1.f;
+                    xv.w = xv.w > 0.f ? xv.w : __expf(xv.w) - 1.f;
+                }
+                acc += (xv.x * wv.x + xv.y * wv.y) + (xv.z * wv.z + xv.w * wv.w);
             }
         }
-        y[m] = acc;
+        for (int off = lps >> 1; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (sub == 0 && m < BT) y[m] = acc + bias[0];
     }
 }
 
 int launch_conv_last(const float* x, const float* w, const float* bias, float* y, int B, long T, int Cin, int k,
-                     hipStream_t s) {
+                     int elu_in, hipStream_t s) {
     const long BT = (long)B * T;
     const int pl = (k - 1) - (k - 1) / 2, pr = (k - 1) / 2;
     const int maxpad = pl > pr ? pl : pr;
     const int Tp = T > maxpad ? (int)T : maxpad + 1;
-    int blocks = (int)((BT + 255) / 256 < 16384 ? (BT + 255) / 256 : 16384);
-    hipLaunchKernelGGL(conv_last_kernel, dim3(blocks), dim3(256), 0, s, x, w, bias, y, BT, (int)T, Cin, k, Tp);
+    if (Cin < 4 || Cin > 256 || (Cin & (Cin - 1))) { set_error("conv_last: Cin must be a power of two in [4, 256]"); return -1; }
+    const long groups = (BT + (256 / (Cin / 4)) - 1) / (256 / (Cin / 4));
+    int blocks = (int)(groups < 16384 ? groups : 16384);
+    hipLaunchKernelGGL(conv_last_kernel, dim3(blocks), dim3(256), 0, s, x, w, bias, y, BT, (int)T, Cin, k, Tp, elu_in);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -69,6 +69,7 @@ __global__ __launch_bounds__(ROWS * 2) void resblock_kernel(const ResblockArgs a
     for (int e = tid; e < L::N1 + C; e += NT)
         bb[e] = e < L::N1 ? (e < L::H ? a.b3[e] : 0.f) : (a.b1[e - L::N1] + a.bs[e - L::N1]);
 
+    const long xbs = a.x_bstride ? a.x_bstride : (long)a.T * C;
     const int tiles_per_clip = (a.T + ROWS - 1) / ROWS;
     const long n_tiles = (long)a.B * tiles_per_clip;
     const int Tp1 = a.T > 1 ? a.T : 2;               // reflect pad 1 (k=3): conv.py:86-91
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(ROWS * 2) void resblock_kernel(const ResblockArgs a
                 pos = pos >= Tp1 ? 2 * (Tp1 - 1) - pos : pos;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (e < L::NX * (C / 4) && pos >= 0 && pos < a.T)
-                    v = *reinterpret_cast<const f32x4*>(a.x + ((long)b * a.T + pos) * C + c4);
+                    v = *reinterpret_cast<const f32x4*>(a.x + (long)b * xbs + (long)pos * C + c4);
                 px[it] = v;
             }
         }
