@@ -510,15 +510,17 @@ int launch_codes_to_features(const int64_t* codes, const float* embed, int K, in
 // order i,f,g,o, plus the skip add.  The recurrence is serial in time, so one launch = one
 // time step of BOTH layers, layer 1 running one step behind layer 0 (launch s: layer 0 step s,
 // layer 1 step s-1).  A workgroup owns 4 hidden units (their 16 gate rows, packed contiguously
-// at load time) for a tile of 64 clips; its 8 waves split K, v_mfma_f32_16x16x4_f32 does the
-// recurrent product, LDS adds the eight K slices, and each thread then updates one (clip, unit)
+// at load time) for a tile of 64 clips; its 16 waves split K, v_mfma_f32_16x16x4_f32 does the
+// recurrent product, LDS adds the sixteen K slices, and each thread then updates one (clip, unit)
 // cell.  Weights stream from L2/Infinity Cache (4-8 MB per layer), h ping-pongs in HBM.
 typedef float f32x4acc __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
-__global__ __launch_bounds__(512) void lstm_step_kernel(const LstmArgs a, int s) {
-    __shared__ float red[8][64][17];
+static constexpr int LSTM_WAVES = 16;
+
+__global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(const LstmArgs a, int s) {
+    __shared__ float red[LSTM_WAVES][64][17];
     const int H = a.H, B = a.B, L = a.L;
     const int nj = H / 4;
     const int layer = blockIdx.x >= nj ? 1 : 0;
@@ -530,7 +532,8 @@ __global__ __launch_bounds__(512) void lstm_step_kernel(const LstmArgs a, int s)
     const int li = lane & 15, lk = lane >> 4;
 
     const int Ktot = layer ? 2 * H : H;
-    const int kw = Ktot / 8;                        // K slice of this wave (64 or 128)
+    const int kw = Ktot / LSTM_WAVES;               // K slice of this wave: 32 (layer 0) or 64 (layer 1)
+    const int nq = kw / 16;                         // 16-wide q-steps in the slice: 2 or 4
     const int kbeg = wave * kw;
     const float* W = (layer ? a.W1 : a.W0) + (long)(bj * 16 + li) * Ktot + kbeg + 4 * lk;
     // source of the K slice: layer 0: h0[t-1]; layer 1: [h0[t] | h1[t-1]]
@@ -563,28 +566,32 @@ __global__ __launch_bounds__(512) void lstm_step_kernel(const LstmArgs a, int s)
         if (layer) x_skip = a.x[((long)cb * L + t) * H + j];
     }
 
+    // the whole K slice of a wave is one batch of loads (one L2 round trip), then its MFMAs; 16 waves
+    // (4 per SIMD) keep the matrix pipe fed while other waves' loads are in flight
     f32x4acc acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = (f32x4acc){0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < kw; k += 64) {
-        // one 64-deep chunk: every load is issued before the first MFMA (one L2 round trip per chunk)
-        f32x4 wv[4], hv[4][4];
+    f32x4 wv[4], hv[4][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) wv[q] = *reinterpret_cast<const f32x4*>(W + k + 16 * q);
+    for (int q = 0; q < 4; ++q) {
+        if (q < nq) {
+            wv[q] = *reinterpret_cast<const f32x4*>(W + 16 * q);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(hrow[i] + k + 16 * q);
+            for (int i = 0; i < 4; ++i) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(hrow[i] + 16 * q);
                 hv[i][q] = hok[i] ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+        }
+    }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 4; ++q) {
+        if (q < nq) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[i][q][e], wv[q][e], acc[i], 0, 0, 0);
+        }
     }
     // C layout 16x16: col = lane & 15 (gate row), row = 4*(lane>>4) + reg (clip)
 #pragma unroll
@@ -598,8 +605,11 @@ __global__ __launch_bounds__(512) void lstm_step_kernel(const LstmArgs a, int s)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int col = g * 4 + jj;
-        g4[g] = (((red[0][br][col] + red[1][br][col]) + (red[2][br][col] + red[3][br][col])) +
-                 ((red[4][br][col] + red[5][br][col]) + (red[6][br][col] + red[7][br][col]))) + gin[g];
+        float v = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < LSTM_WAVES; w8 += 4)
+            v += (red[w8][br][col] + red[w8 + 1][br][col]) + (red[w8 + 2][br][col] + red[w8 + 3][br][col]);
+        g4[g] = v + gin[g];
     }
     const float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]), gg = tanhf(g4[2]), og = sigmoidf_(g4[3]);
     const float c = fg * c_prev + ig * gg;
@@ -615,9 +625,9 @@ __global__ __launch_bounds__(512) void lstm_step_kernel(const LstmArgs a, int s)
 }
 
 int launch_lstm_step(const LstmArgs& a, int s, hipStream_t stream) {
-    if (a.H % 256 != 0) { set_error("lstm: hidden size must be a multiple of 256"); return -1; }
+    if (a.H != 512) { set_error("lstm: the step kernel is built for hidden size 512 (SEANet dimension)"); return -1; }
     dim3 grid(2 * (a.H / 4), (a.B + 63) / 64);
-    hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(512), 0, stream, a, s);
+    hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(64 * LSTM_WAVES), 0, stream, a, s);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }
