@@ -300,3 +300,35 @@ def test_seanet_decoder():
         want = orc.seanet_decoder(z)
     got = m.feature_extractor.encodec.decoder(z.cuda())
     assert rel_l2(got.cpu().numpy(), want.numpy()) < WAV_REL_TOL
+
+
+def test_plan_introspection_and_timing_hook(gpu_model):
+    """wt_plan_* accessors the bench and the debug taps rely on."""
+    import ctypes
+    from wavtokenizer_amd import _capi
+    name, m, _sd = gpu_model
+    wav = torch.from_numpy(load_case(name, "b2_t72000")["wav_in"]).cuda()
+    feats, _ = m.encode_infer(wav, bandwidth_id=BW)
+    m.decode(feats, bandwidth_id=BW)
+    L = feats.shape[-1]
+    plan = m._engine.plans[(_capi.WT_PLAN_DECODE, 2, L, 0)][0]
+    n = _capi.lib.wt_plan_num_steps(plan)
+    names = []
+    for i in range(n):
+        p = ctypes.c_char_p()
+        assert _capi.lib.wt_plan_step_name(plan, i, ctypes.byref(p)) == 0
+        names.append(p.value.decode())
+    assert names.count("cnx.pwconv1") == m.arch.num_layers and "head.istft" in names and "head.ola" in names
+    assert _capi.lib.wt_plan_frames(plan) == L and _capi.lib.wt_plan_num_launches(plan) >= n
+    assert _capi.lib.wt_plan_workspace_bytes(plan) > 0
+    _capi.check(_capi.lib.wt_plan_set_timing(plan, b"cnx.pwconv1"), "set_timing")
+    out1 = m.decode(feats, bandwidth_id=BW)
+    ms, cnt = ctypes.c_double(), ctypes.c_int64()
+    _capi.check(_capi.lib.wt_plan_read_timing(plan, ctypes.byref(ms), ctypes.byref(cnt), 1), "read_timing")
+    _capi.lib.wt_plan_set_timing(plan, b"")
+    assert cnt.value == m.arch.num_layers and 0.0 < ms.value < 1000.0
+    assert torch.equal(out1, m.decode(feats, bandwidth_id=BW))      # timing does not change results
+    off, numel = ctypes.c_size_t(), ctypes.c_size_t()
+    assert _capi.lib.wt_plan_find_buffer(plan, b"bb.out", ctypes.byref(off), ctypes.byref(numel)) == 0
+    assert numel.value == 2 * L * m.arch.dim
+    assert _capi.lib.wt_plan_find_buffer(plan, b"no.such.buffer", ctypes.byref(off), ctypes.byref(numel)) != 0

@@ -26,7 +26,7 @@ void set_error(const std::string& msg);
 //   W  : [N][K] fp32, K contiguous (nn.Linear layout; conv weights repacked to [Cout][tap][Cin]).
 // Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32 multiply-add chain).
 // ---------------------------------------------------------------------------------------------
-enum Pro : int { PRO_NONE = 0, PRO_ELU = 1, PRO_AFFINE = 2, PRO_AFFINE_SWISH = 3 };
+enum Pro : int { PRO_NONE = 0, PRO_ELU = 1 };
 enum Epi : int {
     EPI_BIAS = 0,            // C = acc + bias[n]                        (bias may be null)
     EPI_BIAS_RES = 1,        // C = (acc + bias[n]) + R[m][n]
@@ -48,8 +48,6 @@ struct GemmArgs {
     int T_in = 0, T_out = 0;     // rows per clip in / out;  M = nclips * T_out
     int Cin = 0, taps = 1, stride = 1, dil = 1, pad_left = 0, pad_mode = PAD_ZERO;
     int Tp = 0;           // reflect: effective length max(T_in, max_pad + 1) (conv.py:86-91)
-    const float* pro_scale = nullptr;  // [nclips][Cin]
-    const float* pro_shift = nullptr;
     // W
     const float* W = nullptr;
     long w_rstride = 0;
@@ -76,10 +74,8 @@ struct GemmArgs {
     int group_m = 8;      // tile scheduling group (set by launch_gemm)
 };
 
-enum TileCfg : int { TILE_128x128 = 0, TILE_128x64 = 1, TILE_128x32 = 2, TILE_64x64 = 3 };
 int gemm_vq_parts(int N);   // partial (val, idx) slots per row written by EPI_ARGMAX
 int launch_gemm(const GemmArgs& a, int pro, int epi, hipStream_t s);
-int gemm_init();            // raises dynamic-LDS limits; call once per process/device
 
 // ------------------------------------------------------------------------ non-GEMM kernels
 int launch_conv_first(const float* wav, const float* w /*[7][Cout]*/, const float* bias, float* y, int B, long T,
@@ -91,7 +87,6 @@ int launch_gn_stats(const float* x, const float* gamma, const float* beta, float
                     int C, int groups, float eps, hipStream_t s);
 int launch_gn_apply(const float* x, const float* gamma, const float* beta, float* scale, float* shift, float* y,
                     int swish, int B, int L, int C, int groups, float eps, hipStream_t s);
-int launch_affine(const float* x, const float* scale, const float* shift, float* y, int B, int L, int C, hipStream_t s);
 enum RowNormMode : int { RN_DWCONV = 0, RN_PLAIN = 1, RN_AFFINE_IN = 2 };
 int launch_rownorm(int mode, const float* x, float* y, int B, int L, int C, const float* dw_w /*[7][C]*/,
                    const float* dw_b, const float* in_scale, const float* in_shift, const float* out_scale,

@@ -34,7 +34,6 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 
 // elu: exp(x) - 1 as ATen's CPU kernel evaluates it; __expf keeps the absolute error ~1e-7
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
-__device__ __forceinline__ float swish(float y) { return y / (1.f + expf(-y)); }
 __device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.f + erff(x * 0.70710678118654752440f)); }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int PRO, int EPI>
@@ -111,12 +110,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     // ---- per-thread staging rows (fixed across the K loop)
     const int srow = tid >> 3;        // 0..31
     const int kq4 = (tid & 7) * 4;    // k offset of this thread's float4 inside a K step
-    int a_clipc[NA];                  // clip * Cin (affine prologue table row)
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int m = bm * BM + srow + 32 * i;
-        a_clipc[i] = ((m < p.M ? m : 0) / p.T_out) * p.Cin;
-    }
     unsigned w_off[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -130,7 +123,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     //      kt+1 (already in registers, loaded one iteration earlier) is written to the other LDS buffer
     //      in the MIDDLE of the MFMA block, and the global loads of tile kt+2 are in flight.  Two named
     //      register sets alternate (the loop is unrolled by two so every index is static).
-    struct Stage { f32x4 a[NA]; f32x4 b[NB]; int idx[NA]; };
+    struct Stage { f32x4 a[NA]; f32x4 b[NB]; };
     Stage st0, st1;
     unsigned a_off[NA];               // row offsets of the tap being loaded (registers; refreshed on a tap change)
     auto set_tap = [&](int tap) {
@@ -147,8 +140,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             const unsigned ro = a_off[i];
             const unsigned off = (ro | kmask) + kadv;
             st.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, 0, 0));
-            if (PRO == PRO_AFFINE || PRO == PRO_AFFINE_SWISH)
-                st.idx[i] = (a_clipc[i] + ciL + kq4) | (int)((ro | kmask) & OOB ? -1 : 0);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -166,15 +157,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             f32x4 v = st.a[i];
             if (PRO == PRO_ELU) {                                  // elu(0) = 0: padding stays 0
                 v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w);
-            } else if (PRO == PRO_AFFINE || PRO == PRO_AFFINE_SWISH) {
-                const int idx = st.idx[i] < 0 ? 0 : st.idx[i];
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(p.pro_scale + idx);
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(p.pro_shift + idx);
-                v = v * sc + sh;
-                if (PRO == PRO_AFFINE_SWISH) {
-                    v.x = swish(v.x); v.y = swish(v.y); v.z = swish(v.z); v.w = swish(v.w);
-                }
-                if (st.idx[i] < 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};   // padding is zero AFTER the norm
             }
             *reinterpret_cast<f32x4*>(as + (srow + 32 * i) * LDS_PITCH + kq4) = v;
         }
@@ -398,8 +380,6 @@ static int launch_tiled(const GemmArgs& a, hipStream_t s) {
 }
 
 int gemm_vq_parts(int N) { return ((N + 127) / 128) * 2; }
-
-int gemm_init() { return 0; }
 
 // row-tiles per scheduling group (see the tile remap in the kernel)
 static int pick_group_m(const GemmArgs& a) {

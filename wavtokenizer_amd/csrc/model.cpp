@@ -972,7 +972,6 @@ int wt_model_create(const wt_arch* arch, const wt_tensor* tensors, int32_t n_ten
         for (void* p : M->allocs) (void)hipFree(p);
         return rc;
     }
-    if (int g = gemm_init()) return g;
     *out = M.release();
     return WT_OK;
 }

@@ -221,28 +221,6 @@ int launch_gn_apply(const float* x, const float* gamma, const float* beta, float
     return 0;
 }
 
-__global__ __launch_bounds__(256) void affine_kernel(const float* __restrict__ x, const float* __restrict__ scale,
-                                                     const float* __restrict__ shift, float* __restrict__ y, long n4,
-                                                     int LC4, int C4) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        const long b = i / LC4;
-        const int c4 = (int)(i % C4);
-        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
-        const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[b * C4 + c4];
-        const f32x4 sh = reinterpret_cast<const f32x4*>(shift)[b * C4 + c4];
-        reinterpret_cast<f32x4*>(y)[i] = v * sc + sh;
-    }
-}
-
-int launch_affine(const float* x, const float* scale, const float* shift, float* y, int B, int L, int C,
-                  hipStream_t s) {
-    const long n4 = (long)B * L * C / 4;
-    int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
-    hipLaunchKernelGGL(affine_kernel, dim3(blocks), dim3(256), 0, s, x, scale, shift, y, n4, L * C / 4, C / 4);
-    WT_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-
 // ------------------------------------------------------------------ row LayerNorm (+ dwconv / affine)
 // One wave per frame row of C = NV*256 channels:
 //   RN_DWCONV   : ConvNeXtBlock dwconv k7 p3 groups=C (decoder/modules.py:28,45) then AdaLayerNorm
