@@ -1,4 +1,5 @@
 import os
+import subprocess
 import sys
 
 import pytest
@@ -12,6 +13,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_sessionstart(session):
+    """The HIP library is git-ignored (built in-tree): build it if a fresh checkout has none, so the C-ABI
+    export test and the GPU tests never run against a missing or silently absent extension."""
+    lib = os.path.join(ROOT, "wavtokenizer_amd", "libwavtok_hip.so")
+    if not os.path.exists(lib):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "wavtokenizer_amd", "csrc"), "-j4"], check=True)
 
 
 @pytest.fixture(scope="session")
