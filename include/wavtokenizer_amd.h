@@ -69,7 +69,11 @@ typedef enum {
     WT_PLAN_SEANET_DECODER = 2   /* features (B,512,L) -> audio (B,1,L*hop): encodec.decoder   */
 } wt_plan_kind;
 
-enum { WT_PLAN_FLAG_KEEP_STAGES = 1 };  /* never alias stage buffers (debug taps; bigger workspace) */
+enum {
+    WT_PLAN_FLAG_KEEP_STAGES = 1,  /* never alias stage buffers (debug taps; bigger workspace) */
+    WT_PLAN_FLAG_FP32_GEMM = 2     /* every dense layer on the fp32 MFMA chain; default: the fp32-equivalent
+                                      split-f16 kernel (3 f16 MFMAs per product, fp32 accumulate) where covered */
+};
 
 const char* wt_last_error(void);
 const char* wt_version(void);
@@ -138,6 +142,12 @@ int wt_seanet_decode(const wt_plan* p, const float* features, float* wav_out, vo
 int wt_sconv1d(const float* x, const float* w, const float* bias, float* y, int32_t B, int64_t T,
                int32_t Cin, int32_t Cout, int32_t k, int32_t stride, int32_t dilation, int32_t elu_input,
                void* stream);
+
+/* Replaces: nn.Linear.forward as used by ConvNeXtBlock.pwconv1/2 (decoder/modules.py:52,54): y [M][N] =
+ * x [M][K] . w[N][K]^T + bias.  f16x3 = 0: fp32 MFMA chain; 1: the fp32-equivalent split-f16 kernel
+ * (gemm16.hip; needs K % 32 == 0 and a workspace of 4*N*K bytes for the split weights). */
+int wt_linear(const float* x, const float* w, const float* bias, float* y, int64_t M, int32_t N, int32_t K,
+              int32_t f16x3, void* workspace, void* stream);
 
 /* Replaces: EuclideanCodebook.quantize (encoder/quantization/core_vq.py:175-183): x [N][D] rows,
  * embed [bins][D]; codes_out [N] int64 = argmax_j -(|x|^2 - 2 x.e_j + |e_j|^2), ties -> lowest j.

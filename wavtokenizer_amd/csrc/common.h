@@ -51,6 +51,8 @@ struct GemmArgs {
     // W
     const float* W = nullptr;
     long w_rstride = 0;
+    const void* W_hi = nullptr;    // gemm16 only: f16 hi array [N][K]; the lo array starts w_lo_off halves later
+    long w_lo_off = 0;
     const float* bias = nullptr;
     int M = 0, N = 0, K = 0;
     // C
@@ -76,6 +78,8 @@ struct GemmArgs {
 
 int gemm_vq_parts(int N);   // partial (val, idx) slots per row written by EPI_ARGMAX
 int launch_gemm(const GemmArgs& a, int pro, int epi, hipStream_t s);
+int launch_gemm16(const GemmArgs& a, int epi, hipStream_t s);
+int launch_split_f16x2(const float* w, void* hi, void* lo, long n, hipStream_t s);   // weights -> f16 (hi, lo) arrays   // f16x3-split fp32-equivalent GEMM (gemm16.hip)
 
 // ------------------------------------------------------------------------ non-GEMM kernels
 int launch_conv_first(const float* wav, const float* w /*[7][Cout]*/, const float* bias, float* y, int B, long T,

@@ -62,6 +62,10 @@ struct wt_model {
     std::vector<int> enc_ratios;
     std::vector<void*> allocs;
     int64_t weight_bytes = 0;
+    // f16 (hi, lo) copies of the weight matrices the split-precision GEMM (gemm16.hip) reads, keyed by the
+    // fp32 device pointer the plans already use; `lo_off` = elements between the hi and the lo array
+    struct Split16 { void* hi; long lo_off; };
+    std::map<const float*, Split16> split16;
     // encoder
     float *e0_w = nullptr, *e0_b = nullptr;   // [7][32], [32]
     int e0_k = 7, e0_c = 32;
@@ -433,6 +437,51 @@ static int build_model(wt_model* M, TensorMap& tm) {
     return 0;
 }
 
+static int add_split(wt_model* M, const float* w, long n) {
+    if (!w || n <= 0 || (n % 8)) return 0;
+    void* d = nullptr;
+    WT_HIP_CHECK(hipMalloc(&d, (size_t)n * 4));
+    M->allocs.push_back(d);
+    M->weight_bytes += n * 4;
+    if (int rc = launch_split_f16x2(w, d, static_cast<char*>(d) + (size_t)n * 2, n, nullptr)) return rc;
+    M->split16[w] = {d, n};
+    return 0;
+}
+
+static int build_splits(wt_model* M) {
+    const wt_arch& a = M->arch;
+    const int D = a.dim, I = a.intermediate_dim;
+    auto conv = [&](const ConvW& c) { return add_split(M, c.w, (long)c.cout * c.k * c.cin); };
+    for (const ResStage& st : M->stages) {
+        if (int rc = conv(st.down)) return rc;
+        if (int rc = conv(st.sc)) return rc;
+    }
+    if (int rc = conv(M->enc_final)) return rc;
+    if (int rc = add_split(M, M->enc_lstm.Wih0, 4L * M->H * M->H)) return rc;
+    if (int rc = conv(M->bb_embed)) return rc;
+    for (int i = 0; i < 4; ++i) {
+        if (int rc = conv(M->res[i].c1)) return rc;
+        if (int rc = conv(M->res[i].c2)) return rc;
+    }
+    if (int rc = add_split(M, M->at_Wqk, 2L * D * D)) return rc;
+    if (int rc = add_split(M, M->at_Wp, (long)D * D)) return rc;
+    for (const CnxBlock& c : M->cnx) {
+        if (int rc = add_split(M, c.W1, (long)I * D)) return rc;
+        if (int rc = add_split(M, c.W2, (long)D * I)) return rc;
+    }
+    if (int rc = add_split(M, M->istft_W, 4L * M->Kq * M->Kq)) return rc;
+    if (M->has_seadec) {
+        if (int rc = conv(M->sd_first)) return rc;
+        if (int rc = add_split(M, M->sd_lstm.Wih0, 4L * M->H * M->H)) return rc;
+        for (const SeaDecStage& st : M->sd_stages) {
+            if (st.tr_wp) if (int rc = add_split(M, st.tr_wp, (long)st.r * st.cout * 2 * st.cin)) return rc;
+            if (int rc = conv(st.sc)) return rc;
+        }
+    }
+    WT_HIP_CHECK(hipDeviceSynchronize());
+    return 0;
+}
+
 // --------------------------------------------------------------------------------------- plan
 struct RunCtx {
     char* ws;
@@ -520,6 +569,24 @@ struct wt_plan {
 
 namespace wt {
 
+// Dense layers run on the split-f16 kernel (fp32-equivalent, gemm16.hip) when the weight has a split copy and
+// the shape/epilogue is covered; everything else (ELU prologue, argmax, head, activation x activation
+// products, K % 32 != 0, WT_PLAN_FLAG_FP32_GEMM) on the fp32 MFMA chain of gemm.hip.
+static int gemm_auto(const wt_plan* P, const GemmArgs& a, int pro, int epi, hipStream_t s) {
+    if (!(P->flags & WT_PLAN_FLAG_FP32_GEMM) && pro == PRO_NONE && a.N >= 64 && a.K % 32 == 0 && a.Cin % 8 == 0 &&
+        (a.taps == 1 || a.Cin % 32 == 0) &&
+        (epi == EPI_BIAS || epi == EPI_BIAS_RES || epi == EPI_BIAS_GELU || epi == EPI_BIAS_GAMMA_RES)) {
+        auto it = P->model->split16.find(a.W);
+        if (it != P->model->split16.end() && a.w_rstride % 8 == 0 && a.zW % 8 == 0) {
+            GemmArgs b = a;
+            b.W_hi = it->second.hi;
+            b.w_lo_off = it->second.lo_off;
+            return launch_gemm16(b, epi, s);
+        }
+    }
+    return launch_gemm(a, pro, epi, s);
+}
+
 // SConv1d geometry (encoder/modules/conv.py:195-211, 54-61), non-causal.
 struct SConvGeom { int pl, pr_total, Tout, Tp; };
 static SConvGeom sconv_geom(long T, int k, int stride, int dil) {
@@ -594,18 +661,18 @@ static int plan_resblock(wt_plan* P, const ConvW& c3, const ConvW& c1, const Con
     P->step({xin, h}, [=](const RunCtx& c) {
         GemmArgs a = a3; a.A = P->ptr(c, xin) + x_off; a.C = P->ptr(c, h);
         if (x_bstride) a.a_bstride = x_bstride;
-        return launch_gemm(a, PRO_ELU, EPI_BIAS, c.stream);
+        return gemm_auto(P, a, PRO_ELU, EPI_BIAS, c.stream);
     });
     GemmArgs as = sconv_args(sc, B, T, 1, 1);
     P->step({xin, y}, [=](const RunCtx& c) {
         GemmArgs a = as; a.A = P->ptr(c, xin) + x_off; a.C = P->ptr(c, y);
         if (x_bstride) a.a_bstride = x_bstride;
-        return launch_gemm(a, PRO_NONE, EPI_BIAS, c.stream);
+        return gemm_auto(P, a, PRO_NONE, EPI_BIAS, c.stream);
     });
     GemmArgs a1 = sconv_args(c1, B, T, 1, 1);
     P->step({h, y}, [=](const RunCtx& c) {
         GemmArgs a = a1; a.A = P->ptr(c, h); a.C = P->ptr(c, y); a.R = P->ptr(c, y); a.r_rstride = C;
-        return launch_gemm(a, PRO_ELU, elu_out ? EPI_BIAS_RES_ELU : EPI_BIAS_RES, c.stream);
+        return gemm_auto(P, a, PRO_ELU, elu_out ? EPI_BIAS_RES_ELU : EPI_BIAS_RES, c.stream);
     });
     return y;
 }
@@ -622,7 +689,7 @@ static int plan_lstm(wt_plan* P, const LstmW& w, int B, int L, int H, int xin, c
     ax.T_in = B; ax.T_out = B; ax.a_bstride = H; ax.a_rstride = (long)L * H;
     P->step({xin, xg}, [=](const RunCtx& c) {
         GemmArgs a = ax; a.A = P->ptr(c, xin); a.C = P->ptr(c, xg);
-        return launch_gemm(a, PRO_NONE, EPI_BIAS, c.stream);
+        return gemm_auto(P, a, PRO_NONE, EPI_BIAS, c.stream);
     });
     P->step({xin, xg, st, y}, [=](const RunCtx& c) {
         float* s = P->ptr(c, st);
@@ -666,7 +733,7 @@ static int build_encode(wt_plan* P) {
         const int xin = x;
         P->step({xin, y}, [=](const RunCtx& c) {
             GemmArgs a = ad; a.A = P->ptr(c, xin); a.C = P->ptr(c, y);
-            return launch_gemm(a, fuse_elu ? PRO_NONE : PRO_ELU, EPI_BIAS, c.stream);
+            return gemm_auto(P, a, fuse_elu ? PRO_NONE : PRO_ELU, EPI_BIAS, c.stream);
         });
         x = y; Tc = ad.T_out; idx += 3;
     }
@@ -680,7 +747,7 @@ static int build_encode(wt_plan* P) {
         const int xin = x;
         P->step({xin, emb}, [=](const RunCtx& c) {
             GemmArgs a = af; a.A = P->ptr(c, xin); a.C = P->ptr(c, emb);
-            return launch_gemm(a, fuse_elu ? PRO_NONE : PRO_ELU, EPI_BIAS, c.stream);
+            return gemm_auto(P, a, fuse_elu ? PRO_NONE : PRO_ELU, EPI_BIAS, c.stream);
         });
     }
     // ---- VQ (core_vq.py:175-183, 206-231)
@@ -695,7 +762,7 @@ static int build_encode(wt_plan* P) {
         GemmArgs a = av; a.A = P->ptr(c, emb);
         a.vq_xx = P->ptr(c, xx); a.vq_ee = M->ee; a.vq_pval = P->ptr(c, pv);
         a.vq_pidx = reinterpret_cast<int*>(P->ptr(c, pi)); a.vq_nparts = np;
-        return launch_gemm(a, PRO_NONE, EPI_ARGMAX, c.stream);
+        return gemm_auto(P, a, PRO_NONE, EPI_ARGMAX, c.stream);
     }, 1, "vq.argmin");
     P->step({pv, pi, emb}, [=](const RunCtx& c) {
         if (int rc = launch_vq_finalize(P->ptr(c, pv), reinterpret_cast<int*>(P->ptr(c, pi)), np, M->embed, c.codes,
@@ -718,7 +785,7 @@ static int build_decode(wt_plan* P) {
     GemmArgs ae = zconv_args(M->bb_embed, B, L);
     P->step({x0, x}, [=](const RunCtx& c) {
         GemmArgs a = ae; a.A = P->ptr(c, x0); a.C = P->ptr(c, x);
-        return launch_gemm(a, PRO_NONE, EPI_BIAS, c.stream);
+        return gemm_auto(P, a, PRO_NONE, EPI_BIAS, c.stream);
     });
     const bool keep = P->flags & WT_PLAN_FLAG_KEEP_STAGES;
     auto snapshot = [&](const std::string& name) {   // debug taps of the in-place residual stream
@@ -744,7 +811,7 @@ static int build_decode(wt_plan* P) {
         GemmArgs a1 = zconv_args(r.c1, B, L);
         P->step({h1, h2}, [=](const RunCtx& c) {
             GemmArgs a = a1; a.A = P->ptr(c, h1); a.C = P->ptr(c, h2);
-            return launch_gemm(a, PRO_NONE, EPI_BIAS, c.stream);
+            return gemm_auto(P, a, PRO_NONE, EPI_BIAS, c.stream);
         }, 1, "res.conv1");
         P->step({h2, sc, sh, h1}, [=](const RunCtx& c) {
             return launch_gn_apply(P->ptr(c, h2), r.n2w, r.n2b, P->ptr(c, sc), P->ptr(c, sh), P->ptr(c, h1), 1, B, L, D, 32, 1e-6f, c.stream);
@@ -752,7 +819,7 @@ static int build_decode(wt_plan* P) {
         GemmArgs a2 = zconv_args(r.c2, B, L);
         P->step({h1, x}, [=](const RunCtx& c) {
             GemmArgs a = a2; a.A = P->ptr(c, h1); a.C = P->ptr(c, x); a.R = P->ptr(c, x); a.r_rstride = D;
-            return launch_gemm(a, PRO_NONE, EPI_BIAS_RES, c.stream);
+            return gemm_auto(P, a, PRO_NONE, EPI_BIAS_RES, c.stream);
         }, 1, "res.conv2");
         snapshot(name);
     };
@@ -769,14 +836,14 @@ static int build_decode(wt_plan* P) {
         GemmArgs aqk = linear_args(M->at_Wqk, M->at_bqk, Mrows, 2 * D, D);
         P->step({h1, qk}, [=](const RunCtx& c) {
             GemmArgs a = aqk; a.A = P->ptr(c, h1); a.C = P->ptr(c, qk);
-            return launch_gemm(a, PRO_NONE, EPI_BIAS, c.stream);
+            return gemm_auto(P, a, PRO_NONE, EPI_BIAS, c.stream);
         });
         P->step({h1, vt}, [=](const RunCtx& c) {     // V^T[b] = Wv . hn[b]^T + bv   (D x L, pitch Lp)
             WT_HIP_CHECK(hipMemsetAsync(P->ptr(c, vt), 0, (size_t)B * D * Lp * sizeof(float), c.stream));
             GemmArgs a = linear_args(P->ptr(c, h1), M->at_bv, D, L, D);
             a.A = M->at_Wv; a.zA = 0; a.zW = (long)L * D; a.nz = B;
             a.C = P->ptr(c, vt); a.c_rstride = Lp; a.zC = (long)D * Lp;
-            return launch_gemm(a, PRO_NONE, EPI_BIAS_ROW, c.stream);
+            return gemm_auto(P, a, PRO_NONE, EPI_BIAS_ROW, c.stream);
         }, 2);
         P->step({qk, S}, [=](const RunCtx& c) {      // S[b] = q[b] . k[b]^T * D^-0.5
             GemmArgs a = linear_args(P->ptr(c, qk) + D, nullptr, L, L, D);
@@ -784,19 +851,19 @@ static int build_decode(wt_plan* P) {
             a.w_rstride = 2 * D; a.zW = (long)L * 2 * D; a.nz = B;
             a.C = P->ptr(c, S); a.c_rstride = Lp; a.zC = (long)L * Lp;
             a.alpha = (float)std::pow((double)D, -0.5);
-            return launch_gemm(a, PRO_NONE, EPI_SCALE, c.stream);
+            return gemm_auto(P, a, PRO_NONE, EPI_SCALE, c.stream);
         });
         P->step({S}, [=](const RunCtx& c) { return launch_softmax(P->ptr(c, S), (int)Mrows, L, Lp, c.stream); });
         P->step({S, vt, o}, [=](const RunCtx& c) {   // O[b] = P[b] . V[b]
             GemmArgs a = linear_args(P->ptr(c, vt), nullptr, L, D, Lp);
             a.A = P->ptr(c, S); a.zA = (long)L * Lp; a.zW = (long)D * Lp; a.nz = B;
             a.C = P->ptr(c, o); a.c_rstride = D; a.zC = (long)L * D;
-            return launch_gemm(a, PRO_NONE, EPI_BIAS, c.stream);
+            return gemm_auto(P, a, PRO_NONE, EPI_BIAS, c.stream);
         });
         GemmArgs ap = linear_args(M->at_Wp, M->at_bp, Mrows, D, D);
         P->step({o, x}, [=](const RunCtx& c) {
             GemmArgs a = ap; a.A = P->ptr(c, o); a.C = P->ptr(c, x); a.R = P->ptr(c, x); a.r_rstride = D;
-            return launch_gemm(a, PRO_NONE, EPI_BIAS_RES, c.stream);
+            return gemm_auto(P, a, PRO_NONE, EPI_BIAS_RES, c.stream);
         });
         snapshot("bb.pos_net.2");
     }
@@ -830,12 +897,12 @@ static int build_decode(wt_plan* P) {
         GemmArgs a1 = linear_args(cb.W1, cb.b1, Mrows, I, D);
         P->step({nrm, mid}, [=](const RunCtx& c) {
             GemmArgs a = a1; a.A = P->ptr(c, nrm); a.C = P->ptr(c, mid);
-            return launch_gemm(a, PRO_NONE, EPI_BIAS_GELU, c.stream);
+            return gemm_auto(P, a, PRO_NONE, EPI_BIAS_GELU, c.stream);
         }, 1, "cnx.pwconv1");
         GemmArgs a2 = linear_args(cb.W2, cb.b2, Mrows, D, I);
         P->step({mid, xc}, [=](const RunCtx& c) {
             GemmArgs a = a2; a.A = P->ptr(c, mid); a.C = P->ptr(c, xc); a.R = P->ptr(c, xc); a.r_rstride = D; a.gamma = cb.gamma;
-            return launch_gemm(a, PRO_NONE, EPI_BIAS_GAMMA_RES, c.stream);
+            return gemm_auto(P, a, PRO_NONE, EPI_BIAS_GAMMA_RES, c.stream);
         }, 1, "cnx.pwconv2");
         if (keep && (i == 0 || i == ar.num_layers / 2 - 1 || i == ar.num_layers - 1)) {
             const int s = P->buf("bb.convnext." + std::to_string(i), (size_t)Mrows * D);
@@ -858,7 +925,7 @@ static int build_decode(wt_plan* P) {
     GemmArgs ah = linear_args(M->head_W, M->head_b, Mrows, 2 * Kb, D);
     P->step({xo, spec}, [=](const RunCtx& c) {
         GemmArgs a = ah; a.A = P->ptr(c, xo); a.C = P->ptr(c, spec); a.c_rstride = 2 * Kb; a.head_kb = Kb;
-        return launch_gemm(a, PRO_NONE, EPI_HEAD, c.stream);
+        return gemm_auto(P, a, PRO_NONE, EPI_HEAD, c.stream);
     }, 1, "head.out");
     // ISTFT (spectral_ops.py:56-73): four quarter-size real transforms as one batched GEMM, then the
     // butterflies + window + overlap-add + trim + envelope divide in one pass
@@ -869,7 +936,7 @@ static int build_decode(wt_plan* P) {
         a.A = P->ptr(c, spec); a.a_rstride = 2 * Kb; a.zA = Kq;              // z picks the spectrum quarter
         a.zW = (long)Kq * Kq; a.nz = 4;
         a.C = P->ptr(c, parts); a.c_rstride = Kq; a.zC = (long)Mrows * Kq;
-        return launch_gemm(a, PRO_NONE, EPI_BIAS, c.stream);
+        return gemm_auto(P, a, PRO_NONE, EPI_BIAS, c.stream);
     }, 1, "head.istft");
     P->step({parts}, [=](const RunCtx& c) {
         return launch_istft_ola(P->ptr(c, parts), M->win, M->wsq, c.out_f, B, L, ar.n_fft, hop, Kq, c.stream);
@@ -889,7 +956,7 @@ static int build_seanet_decoder(wt_plan* P) {
         const int y = x;
         P->step({x0, y}, [=](const RunCtx& c) {
             GemmArgs a = a0; a.A = P->ptr(c, x0); a.C = P->ptr(c, y);
-            return launch_gemm(a, PRO_NONE, EPI_BIAS, c.stream);
+            return gemm_auto(P, a, PRO_NONE, EPI_BIAS, c.stream);
         });
     }
     const bool fuse_elu = !(P->flags & WT_PLAN_FLAG_KEEP_STAGES);      // producers store elu(.) for "ELU -> conv" consumers
@@ -919,7 +986,7 @@ static int build_seanet_decoder(wt_plan* P) {
                 a.W = st.tr_wp; a.w_rstride = 2L * st.cin; a.zW = (long)st.cout * 2 * st.cin; a.bias = st.tr_b;
                 a.M = B * (Tin + 1); a.N = st.cout; a.K = 2 * st.cin;
                 a.C = P->ptr(c, y); a.c_rstride = (long)st.r * st.cout; a.zC = st.cout; a.nz = st.r;
-                return launch_gemm(a, fuse_elu ? PRO_NONE : PRO_ELU, EPI_BIAS, c.stream);
+                return gemm_auto(P, a, fuse_elu ? PRO_NONE : PRO_ELU, EPI_BIAS, c.stream);
             }, 1, "sdec.convtr");
         } else {
             y = P->buf("sdec." + std::to_string(di + 1), (size_t)B * To * st.cout);
@@ -967,6 +1034,7 @@ int wt_model_create(const wt_arch* arch, const wt_tensor* tensors, int32_t n_ten
     TensorMap tm;
     for (int i = 0; i < n_tensors; ++i) tm.m[tensors[i].name] = {tensors[i].data, tensors[i].numel};
     int rc = build_model(M.get(), tm);
+    if (!rc) rc = build_splits(M.get());
     if (rc) {
         if (rc == WT_ERR_MISSING_TENSOR) set_error("state_dict tensor missing or mis-shaped: " + tm.missing);
         for (void* p : M->allocs) (void)hipFree(p);
@@ -1127,6 +1195,20 @@ int wt_sconv1d(const float* x, const float* w, const float* bias, float* y, int3
     GemmArgs a = sconv_args(cw, B, T, stride, dilation);
     a.A = x; a.C = y;
     return launch_gemm(a, elu_input ? PRO_ELU : PRO_NONE, EPI_BIAS, static_cast<hipStream_t>(stream));
+}
+
+int wt_linear(const float* x, const float* w, const float* bias, float* y, int64_t M, int32_t N, int32_t K,
+              int32_t f16x3, void* workspace, void* stream) {
+    if (!x || !w || !y) { set_error("wt_linear: null argument"); return WT_ERR_INVALID; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GemmArgs a = linear_args(w, bias, M, N, K);
+    a.A = x; a.C = y;
+    if (!f16x3) return launch_gemm(a, PRO_NONE, EPI_BIAS, s);
+    if (!workspace) { set_error("wt_linear: the f16x3 mode needs a workspace of 4*N*K bytes"); return WT_ERR_INVALID; }
+    char* hi = static_cast<char*>(workspace);
+    if (int rc = launch_split_f16x2(w, hi, hi + (size_t)N * K * 2, (long)N * K, s)) return rc;
+    a.W_hi = hi; a.w_lo_off = (long)N * K;
+    return launch_gemm16(a, EPI_BIAS, s);
 }
 
 size_t wt_vq_workspace_bytes(int64_t N, int32_t bins) {

@@ -322,7 +322,16 @@ class WavTokenizer(nn.Module):
 
     def set_debug_keep_stages(self, on: bool):
         """Parity tests: keep every stage buffer of the next plans distinct in the workspace."""
-        self._plan_flags = _capi.WT_PLAN_FLAG_KEEP_STAGES if on else 0
+        self._plan_flags = (self._plan_flags | _capi.WT_PLAN_FLAG_KEEP_STAGES) if on else \
+            (self._plan_flags & ~_capi.WT_PLAN_FLAG_KEEP_STAGES)
+
+    def set_gemm_precision(self, mode: str):
+        """"f16x3" (default): dense layers on the fp32-equivalent split-f16 MFMA kernel; "f32": the plain
+        fp32 MFMA chain everywhere.  Both accumulate in fp32; measured error vs float64 is lower for f16x3."""
+        if mode not in ("f16x3", "f32"):
+            raise ValueError("mode must be 'f16x3' or 'f32'")
+        self._plan_flags = (self._plan_flags | _capi.WT_PLAN_FLAG_FP32_GEMM) if mode == "f32" else \
+            (self._plan_flags & ~_capi.WT_PLAN_FLAG_FP32_GEMM)
 
     @property
     def arch(self) -> ArchConfig:
