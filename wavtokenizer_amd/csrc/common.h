@@ -78,7 +78,8 @@ struct GemmArgs {
 
 int gemm_vq_parts(int N);   // partial (val, idx) slots per row written by EPI_ARGMAX
 int launch_gemm(const GemmArgs& a, int pro, int epi, hipStream_t s);
-int launch_gemm16(const GemmArgs& a, int epi, hipStream_t s);
+int launch_gemm16(const GemmArgs& a, int pro, int epi, hipStream_t s);
+int gemm16_vq_parts(int N);
 int launch_split_f16x2(const float* w, void* hi, void* lo, long n, hipStream_t s);   // weights -> f16 (hi, lo) arrays   // f16x3-split fp32-equivalent GEMM (gemm16.hip)
 
 // ------------------------------------------------------------------------ non-GEMM kernels

@@ -14,6 +14,7 @@
 #include "common.h"
 
 #include <cmath>
+#include <stdlib.h>
 
 namespace wt {
 
@@ -32,9 +33,10 @@ __device__ __forceinline__ int xcd_remap16(int orig, int nwg) {
     int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + idx;
 }
+__device__ __forceinline__ float elu16(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
 __device__ __forceinline__ float gelu_erf16(float x) { return x * 0.5f * (1.f + erff(x * 0.70710678118654752440f)); }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PRO, int EPI>
 __global__ __launch_bounds__(256) void gemm16_kernel(const GemmArgs p) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -137,7 +139,8 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const GemmArgs p) {
         _Float16* base = lds + buf * BUF;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const f32x4 v = st.a[i];
+            f32x4 v = st.a[i];
+            if (PRO == PRO_ELU) { v.x = elu16(v.x); v.y = elu16(v.y); v.z = elu16(v.z); v.w = elu16(v.w); }   // elu(0) = 0
             f16x4 hi, lo;
             hi.x = (_Float16)v.x; hi.y = (_Float16)v.y; hi.z = (_Float16)v.z; hi.w = (_Float16)v.w;
             lo.x = (_Float16)((v.x - (float)hi.x) * 2048.f);
@@ -210,6 +213,65 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const GemmArgs p) {
     float* __restrict__ Cg = p.C + (long)z * p.zC;
     constexpr float LO_SCALE = 1.f / 2048.f;
 
+    if constexpr (EPI == EPI_ARGMAX) {
+        // VQ (core_vq.py:176-182): best of this wave's WN columns for each of its WM rows
+        const int part = bn * WAVES_N + wn;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_w + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+                const float xx = (m < p.M) ? p.vq_xx[m] : 0.f;
+                float best = -INFINITY;
+                int bidx = 0x7fffffff;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n_w + j * 32 + col_l;
+                    if (n < p.N) {
+                        const float dot = accm[i][j][r] + accc[i][j][r] * LO_SCALE;
+                        const float d = -((xx - 2.f * dot) + p.vq_ee[n]);
+                        if (d > best || (d == best && n < bidx)) { best = d; bidx = n; }
+                    }
+                }
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) {
+                    const float ov = __shfl_xor(best, off, 64);
+                    const int oi = __shfl_xor(bidx, off, 64);
+                    if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+                }
+                if (col_l == 0 && m < p.M) {
+                    p.vq_pval[(long)m * p.vq_nparts + part] = best;
+                    p.vq_pidx[(long)m * p.vq_nparts + part] = bidx;
+                }
+            }
+        }
+        return;
+    }
+    if constexpr (EPI == EPI_HEAD) {
+        static_assert(TN % 2 == 0, "head epilogue pairs column tiles");
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j + 1 < TN; j += 2) {
+                const int pc = n_w + j * 32 + col_l;
+                if (pc < p.N) {
+                    const float bmag = p.bias[pc], bph = p.bias[pc + 32];
+                    const int f = (pc >> 6) * 32 + col_l;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m_w + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+                        if (m < p.M) {
+                            float mag = expf(accm[i][j][r] + accc[i][j][r] * LO_SCALE + bmag);      // heads.py:55
+                            mag = fminf(mag, 100.f);                                             // heads.py:56
+                            const float ph = accm[i][j + 1][r] + accc[i][j + 1][r] * LO_SCALE + bph;
+                            Cg[(long)m * p.c_rstride + f] = mag * cosf(ph);
+                            Cg[(long)m * p.c_rstride + p.head_kb + f] = mag * sinf(ph);
+                        }
+                    }
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -228,6 +290,8 @@ __global__ __launch_bounds__(256) void gemm16_kernel(const GemmArgs p) {
                     Cg[(long)m * p.c_rstride + n] = v + bn_;
                 } else if (EPI == EPI_BIAS_RES) {
                     Cg[(long)m * p.c_rstride + n] = (v + bn_) + p.R[(long)m * p.r_rstride + n];
+                } else if (EPI == EPI_BIAS_RES_ELU) {
+                    Cg[(long)m * p.c_rstride + n] = elu16((v + bn_) + p.R[(long)m * p.r_rstride + n]);
                 } else if (EPI == EPI_BIAS_GELU) {
                     Cg[(long)m * p.c_rstride + n] = gelu_erf16(v + bn_);
                 } else if (EPI == EPI_BIAS_GAMMA_RES) {
@@ -257,12 +321,12 @@ int launch_split_f16x2(const float* w, void* hi, void* lo, long n, hipStream_t s
 }
 
 // ---------------------------------------------------------------------------------- host side
-template <int BM, int BN, int WMs, int WNs, int EPI>
+template <int BM, int BN, int WMs, int WNs, int PRO, int EPI>
 static int launch16_one(const GemmArgs& a, hipStream_t s) {
     static bool attr_set = false;
     const size_t smem = 2ull * (2 * BM + 2 * BN) * PITCH16 * sizeof(_Float16) + (size_t)a.taps * BM * sizeof(unsigned);
     constexpr size_t smem_max = 2ull * (2 * BM + 2 * BN) * PITCH16 * sizeof(_Float16) + 32ull * BM * sizeof(unsigned);
-    auto kern = gemm16_kernel<BM, BN, WMs, WNs, EPI>;
+    auto kern = gemm16_kernel<BM, BN, WMs, WNs, PRO, EPI>;
     if (!attr_set) {
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)smem_max));
@@ -274,21 +338,35 @@ static int launch16_one(const GemmArgs& a, hipStream_t s) {
     return 0;
 }
 
-template <int EPI>
+template <int PRO, int EPI>
 static int launch16_tiled(const GemmArgs& a, hipStream_t s) {
-    // 128x96 (wave tile 32x96) or 128x64 by the slot-rounding cost of gemm.hip; the two accumulator sets
-    // rule out 128x128 (register budget)
-    const long tm = (a.M + 127) / 128;
-    auto cost = [&](int bn, double eff) {
-        const long t = tm * ((a.N + bn - 1) / bn) * a.nz;
-        return std::ceil((double)t / 512.0) * bn / eff;
-    };
-    if (cost(64, 0.85) < cost(96, 1.0)) return launch16_one<128, 64, 2, 2, EPI>(a, s);
-    return launch16_one<128, 96, 4, 1, EPI>(a, s);
+    if constexpr (EPI == EPI_HEAD || EPI == EPI_ARGMAX) {
+        // paired column tiles / per-wave column slabs: 128x64 with the waves stacked along M (wave tile 32x64)
+        return launch16_one<128, 64, 4, 1, PRO, EPI>(a, s);
+    } else {
+        // 128x96 (wave tile 32x96) or 128x64 by the slot-rounding cost of gemm.hip; the two accumulator sets
+        // rule out 128x128 (register budget)
+        const long tm = (a.M + 127) / 128;
+        auto cost = [&](int bn, double eff) {
+            const long t = tm * ((a.N + bn - 1) / bn) * a.nz;
+            return std::ceil((double)t / 512.0) * bn / eff;
+        };
+        if constexpr (PRO == PRO_NONE && EPI == EPI_BIAS) {       // experiment hook (tools/linear_bench.py)
+            static int ov = -2;
+            if (ov == -2) { const char* e = getenv("WT_GEMM16_TILE"); ov = e ? atoi(e) : -1; }
+            if (ov == 128) return launch16_one<128, 128, 2, 2, PRO, EPI>(a, s);
+            if (ov == 64) return launch16_one<128, 64, 2, 2, PRO, EPI>(a, s);
+            if (ov == 96) return launch16_one<128, 96, 4, 1, PRO, EPI>(a, s);
+        }
+        if (cost(64, 0.85) < cost(96, 1.0)) return launch16_one<128, 64, 2, 2, PRO, EPI>(a, s);
+        return launch16_one<128, 96, 4, 1, PRO, EPI>(a, s);
+    }
 }
 
-// same contract as launch_gemm with PRO_NONE; needs a.W_hi (f16 [N][K] hi array, lo array w_lo_off halves later) instead of a.W
-int launch_gemm16(const GemmArgs& a_in, int epi, hipStream_t s) {
+int gemm16_vq_parts(int N) { return (N + 63) / 64; }
+
+// same contract as launch_gemm; needs a.W_hi (f16 [N][K] hi array, lo array w_lo_off halves later) instead of a.W
+int launch_gemm16(const GemmArgs& a_in, int pro, int epi, hipStream_t s) {
     const GemmArgs& c = a_in;
     if (c.M <= 0 || c.N <= 0 || c.K <= 0 || c.K % BK16 || c.Cin % 8 || (c.taps > 1 && c.Cin % BK16) || c.K != c.taps * c.Cin ||
         c.T_out <= 0 || c.M % c.T_out || c.taps > 32 || !c.W_hi || c.w_lo_off <= 0 || (c.w_lo_off % 8) || (c.w_rstride % 8) || (c.zW % 8) ||
@@ -306,13 +384,19 @@ int launch_gemm16(const GemmArgs& a_in, int epi, hipStream_t s) {
     GemmArgs a = a_in;
     const int bn = 96;
     a.group_m = (a.N + bn - 1) / bn > 8 ? 8 : 1;
-    switch (epi) {
-        case EPI_BIAS: return launch16_tiled<EPI_BIAS>(a, s);
-        case EPI_BIAS_RES: return launch16_tiled<EPI_BIAS_RES>(a, s);
-        case EPI_BIAS_GELU: return launch16_tiled<EPI_BIAS_GELU>(a, s);
-        case EPI_BIAS_GAMMA_RES: return launch16_tiled<EPI_BIAS_GAMMA_RES>(a, s);
-        default: set_error("gemm16: unsupported epilogue"); return -1;
-    }
+#define WT_CASE16(P, E) if (pro == P && epi == E) return launch16_tiled<P, E>(a, s);
+    WT_CASE16(PRO_NONE, EPI_BIAS)
+    WT_CASE16(PRO_NONE, EPI_BIAS_RES)
+    WT_CASE16(PRO_NONE, EPI_BIAS_GELU)
+    WT_CASE16(PRO_NONE, EPI_BIAS_GAMMA_RES)
+    WT_CASE16(PRO_NONE, EPI_HEAD)
+    WT_CASE16(PRO_NONE, EPI_ARGMAX)
+    WT_CASE16(PRO_ELU, EPI_BIAS)
+    WT_CASE16(PRO_ELU, EPI_BIAS_RES)
+    WT_CASE16(PRO_ELU, EPI_BIAS_RES_ELU)
+#undef WT_CASE16
+    set_error("gemm16: unsupported prologue/epilogue pair");
+    return -1;
 }
 
 }  // namespace wt

@@ -455,7 +455,11 @@ static int build_splits(wt_model* M) {
     for (const ResStage& st : M->stages) {
         if (int rc = conv(st.down)) return rc;
         if (int rc = conv(st.sc)) return rc;
+        if (int rc = conv(st.c3)) return rc;
+        if (int rc = conv(st.c1)) return rc;
     }
+    if (int rc = add_split(M, M->embed, (long)a.vq_bins * 512)) return rc;
+    if (int rc = add_split(M, M->head_W, 2L * M->Kb * D)) return rc;
     if (int rc = conv(M->enc_final)) return rc;
     if (int rc = add_split(M, M->enc_lstm.Wih0, 4L * M->H * M->H)) return rc;
     if (int rc = conv(M->bb_embed)) return rc;
@@ -476,6 +480,8 @@ static int build_splits(wt_model* M) {
         for (const SeaDecStage& st : M->sd_stages) {
             if (st.tr_wp) if (int rc = add_split(M, st.tr_wp, (long)st.r * st.cout * 2 * st.cin)) return rc;
             if (int rc = conv(st.sc)) return rc;
+            if (int rc = conv(st.c3)) return rc;
+            if (int rc = conv(st.c1)) return rc;
         }
     }
     WT_HIP_CHECK(hipDeviceSynchronize());
@@ -572,17 +578,21 @@ namespace wt {
 // Dense layers run on the split-f16 kernel (fp32-equivalent, gemm16.hip) when the weight has a split copy and
 // the shape/epilogue is covered; everything else (ELU prologue, argmax, head, activation x activation
 // products, K % 32 != 0, WT_PLAN_FLAG_FP32_GEMM) on the fp32 MFMA chain of gemm.hip.
+static bool gemm16_covers(const wt_plan* P, const GemmArgs& a, int pro, int epi) {
+    if (P->flags & WT_PLAN_FLAG_FP32_GEMM) return false;
+    if (a.N < 64 || a.K % 32 || a.Cin % 8 || (a.taps > 1 && a.Cin % 32) || a.w_rstride % 8 || a.zW % 8) return false;
+    const bool ok_pair = (pro == PRO_NONE && (epi == EPI_BIAS || epi == EPI_BIAS_RES || epi == EPI_BIAS_GELU ||
+                                               epi == EPI_BIAS_GAMMA_RES || epi == EPI_HEAD || epi == EPI_ARGMAX)) ||
+                         (pro == PRO_ELU && (epi == EPI_BIAS || epi == EPI_BIAS_RES || epi == EPI_BIAS_RES_ELU));
+    return ok_pair && P->model->split16.count(a.W) != 0;
+}
 static int gemm_auto(const wt_plan* P, const GemmArgs& a, int pro, int epi, hipStream_t s) {
-    if (!(P->flags & WT_PLAN_FLAG_FP32_GEMM) && pro == PRO_NONE && a.N >= 64 && a.K % 32 == 0 && a.Cin % 8 == 0 &&
-        (a.taps == 1 || a.Cin % 32 == 0) &&
-        (epi == EPI_BIAS || epi == EPI_BIAS_RES || epi == EPI_BIAS_GELU || epi == EPI_BIAS_GAMMA_RES)) {
-        auto it = P->model->split16.find(a.W);
-        if (it != P->model->split16.end() && a.w_rstride % 8 == 0 && a.zW % 8 == 0) {
-            GemmArgs b = a;
-            b.W_hi = it->second.hi;
-            b.w_lo_off = it->second.lo_off;
-            return launch_gemm16(b, epi, s);
-        }
+    if (gemm16_covers(P, a, pro, epi)) {
+        const auto& sp = P->model->split16.at(a.W);
+        GemmArgs b = a;
+        b.W_hi = sp.hi;
+        b.w_lo_off = sp.lo_off;
+        return launch_gemm16(b, pro, epi, s);
     }
     return launch_gemm(a, pro, epi, s);
 }
@@ -752,12 +762,14 @@ static int build_encode(wt_plan* P) {
     }
     // ---- VQ (core_vq.py:175-183, 206-231)
     const int bins = M->arch.vq_bins;
-    const int np = gemm_vq_parts(bins);
+    GemmArgs av = linear_args(M->embed, nullptr, (long)B * L, bins, 512);
+    // the argmax epilogue leaves one (value, index) candidate per wave column slab; their number depends on
+    // which kernel the distance GEMM runs on
+    const int np = gemm16_covers(P, av, PRO_NONE, EPI_ARGMAX) ? gemm16_vq_parts(bins) : gemm_vq_parts(bins);
     const int xx = P->buf("vq.xx", (size_t)B * L);
     const int pv = P->buf("vq.pval", (size_t)B * L * np);
     const int pi = P->buf("vq.pidx", (size_t)B * L * np);
     P->step({emb, xx}, [=](const RunCtx& c) { return launch_row_sumsq(P->ptr(c, emb), P->ptr(c, xx), (long)B * L, 512, c.stream); });
-    GemmArgs av = linear_args(M->embed, nullptr, (long)B * L, bins, 512);
     P->step({emb, xx, pv, pi}, [=](const RunCtx& c) {
         GemmArgs a = av; a.A = P->ptr(c, emb);
         a.vq_xx = P->ptr(c, xx); a.vq_ee = M->ee; a.vq_pval = P->ptr(c, pv);
@@ -1208,7 +1220,7 @@ int wt_linear(const float* x, const float* w, const float* bias, float* y, int64
     char* hi = static_cast<char*>(workspace);
     if (int rc = launch_split_f16x2(w, hi, hi + (size_t)N * K * 2, (long)N * K, s)) return rc;
     a.W_hi = hi; a.w_lo_off = (long)N * K;
-    return launch_gemm16(a, EPI_BIAS, s);
+    return launch_gemm16(a, PRO_NONE, EPI_BIAS, s);
 }
 
 size_t wt_vq_workspace_bytes(int64_t N, int32_t bins) {
