@@ -145,9 +145,18 @@ int wt_sconv1d(const float* x, const float* w, const float* bias, float* y, int3
 
 /* Replaces: nn.Linear.forward as used by ConvNeXtBlock.pwconv1/2 (decoder/modules.py:52,54): y [M][N] =
  * x [M][K] . w[N][K]^T + bias.  f16x3 = 0: fp32 MFMA chain; 1: the fp32-equivalent split-f16 kernel
- * (gemm16.hip; needs K % 32 == 0 and a workspace of 4*N*K bytes for the split weights). */
+ * (gemm16.hip; needs K % 32 == 0 and a workspace of 4*N*K bytes for the split weights); 2: the same arithmetic on
+ * pre-split "S32" operands staged by LDS-DMA (gemm16s.hip: the plans' producers write S32 directly; here x and w
+ * are split into the workspace first, 4*(M+N)*K bytes, K % 32 == 0); 3: as 2 and y is written in S32 too
+ * (N % 32 == 0; every 32 outputs of a row = 128 bytes [32 x f16 hi | 32 x f16 lo], value = hi + lo * 2^-11). */
 int wt_linear(const float* x, const float* w, const float* bias, float* y, int64_t M, int32_t N, int32_t K,
               int32_t f16x3, void* workspace, void* stream);
+
+/* Conv1d on the S32 split-f16 kernel (gemm16s.hip), time-major x [B][T][Cin] -> y [B][Tout][Cout] fp32,
+ * w [Cout][k][Cin]: zero_same = 1: nn.Conv1d(k, padding=(k-1)/2) as in decoder/models.py:29-43,177 (stride 1);
+ * zero_same = 0: SConv1d reflect padding (conv.py:195-211).  Cin % 32 == 0; workspace 4*(B*T*Cin + Cout*k*Cin) bytes. */
+int wt_conv1d_s32(const float* x, const float* w, const float* bias, float* y, int32_t B, int64_t T, int32_t Cin,
+                  int32_t Cout, int32_t k, int32_t stride, int32_t zero_same, void* workspace, void* stream);
 
 /* Replaces: EuclideanCodebook.quantize (encoder/quantization/core_vq.py:175-183): x [N][D] rows,
  * embed [bins][D]; codes_out [N] int64 = argmax_j -(|x|^2 - 2 x.e_j + |e_j|^2), ties -> lowest j.

@@ -257,6 +257,86 @@ def test_sconv1d_kernel(B, T, Cin, Cout, k, stride, dil, elu):
     assert rel_l2(y.permute(0, 2, 1).cpu().numpy(), want.numpy()) < 1e-5
 
 
+def _decode_s32(y, M, N):
+    """S32 (gemm16s.hip): every 32 values of a row are 128 bytes [32 x f16 hi | 32 x f16 lo], value = hi + lo / 2048."""
+    h = y.view(torch.float16).view(M, N // 32, 2, 32).double()
+    return (h[:, :, 0, :] + h[:, :, 1, :] / 2048.0).reshape(M, N)
+
+
+@pytest.mark.parametrize("M,N,K", [(7680, 2304, 768), (1000, 800, 96), (1, 32, 32), (129, 196, 64), (300, 96, 2304)])
+def test_linear_s32_kernel(M, N, K):
+    """wt_linear on the S32 split-f16 / LDS-DMA kernel (modes 2, 3) against float64: fp32-equivalent products,
+    ragged row and column tiles, S32-encoded output."""
+    from wavtokenizer_amd._capi import lib, check
+    gen = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=gen) * torch.exp(0.5 * torch.randn(M, K, generator=gen))).cuda()
+    w = (torch.randn(N, K, generator=gen) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=gen).cuda()
+    ws = torch.empty(4 * (M + N) * K + 1024, dtype=torch.uint8, device="cuda")
+    ref = x.double() @ w.double().t() + b.double()
+    for mode in (2, 3):
+        if mode == 3 and N % 32:
+            continue
+        y = torch.full((M, N), float("nan"), device="cuda")
+        check(lib.wt_linear(_ptr(x), _ptr(w), _ptr(b), _ptr(y), M, N, K, mode, _ptr(ws), None), "wt_linear")
+        torch.cuda.synchronize()
+        got = _decode_s32(y, M, N) if mode == 3 else y.double()
+        assert torch.isfinite(got).all()
+        assert ((got - ref).norm() / ref.norm()).item() < 1e-6
+        assert (got - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("B,T,Cin,Cout,k,stride,zero_same", [
+    (4, 120, 768, 768, 3, 1, 1), (3, 225, 512, 768, 7, 1, 1), (2, 1, 768, 768, 3, 1, 1), (2, 2, 64, 96, 7, 1, 1),
+    (3, 777, 32, 64, 8, 4, 0), (2, 333, 64, 128, 10, 5, 0), (1, 50, 256, 512, 12, 6, 0), (2, 5, 512, 512, 7, 1, 0),
+    (1, 3, 32, 64, 16, 8, 0),
+])
+def test_conv1d_s32_kernel(B, T, Cin, Cout, k, stride, zero_same):
+    """wt_conv1d_s32 (S32 operands, LDS-DMA gather: an out-of-range row offset must read as zeros) against
+    nn.Conv1d 'same' zero padding (decoder/models.py:29-43) and SConv1d reflect padding (conv.py:195-211)."""
+    import torch.nn.functional as F
+    from oracle.cpu_ref import get_extra_padding_for_conv1d, pad1d_reflect
+    from wavtokenizer_amd._capi import lib, check
+    gen = torch.Generator().manual_seed(B * 1000 + T + k + Cin)
+    x = torch.randn(B, Cin, T, generator=gen)
+    w = torch.randn(Cout, Cin, k, generator=gen) / (Cin * k) ** 0.5
+    b = torch.randn(Cout, generator=gen)
+    if zero_same:
+        want = F.conv1d(x.double(), w.double(), b.double(), padding=(k - 1) // 2)
+    else:
+        pt = k - stride
+        extra = get_extra_padding_for_conv1d(T, k, stride, pt)
+        pr = pt // 2
+        want = F.conv1d(pad1d_reflect(x, (pt - pr, pr + extra)).double(), w.double(), b.double(), stride=stride)
+    Tout = want.shape[-1]
+    xg = x.permute(0, 2, 1).contiguous().cuda()
+    wg = w.permute(0, 2, 1).contiguous().cuda()      # [Cout][k][Cin]
+    bg = b.cuda()
+    y = torch.full((B, Tout, Cout), float("nan"), device="cuda")
+    ws = torch.empty(4 * (B * T * Cin + Cout * k * Cin) + 1024, dtype=torch.uint8, device="cuda")
+    check(lib.wt_conv1d_s32(_ptr(xg), _ptr(wg), _ptr(bg), _ptr(y), B, T, Cin, Cout, k, stride, zero_same, _ptr(ws), None),
+          "wt_conv1d_s32")
+    torch.cuda.synchronize()
+    assert rel_l2(y.permute(0, 2, 1).cpu().numpy(), want.numpy()) < 1e-6
+
+
+def test_s32_decode_path_matches_the_fp32_chain(gpu_model):
+    """decode() on the default plan (S32 operands end to end) against the same model forced onto the fp32 MFMA chain."""
+    name, m, sd = gpu_model
+    from wavtokenizer_amd import synth
+    wav = torch.from_numpy(synth.make_clips(3, 24000, seed=77)).cuda()
+    feats, codes = m.encode_infer(wav, bandwidth_id=BW)
+    out = m.decode(feats, bandwidth_id=BW)
+    m.set_gemm_precision("f32")
+    try:
+        feats32, codes32 = m.encode_infer(wav, bandwidth_id=BW)
+        out32 = m.decode(feats32, bandwidth_id=BW)
+    finally:
+        m.set_gemm_precision("f16x3")
+    assert torch.equal(codes, codes32)
+    assert rel_l2(out.cpu().numpy(), out32.cpu().numpy()) < 2e-5
+
+
 def test_vq_nearest_kernel_and_ties():
     """wt_vq_nearest vs core_vq.py:175-183 on CPU; duplicated codebook rows tie -> lowest index."""
     from wavtokenizer_amd._capi import lib, check

@@ -18,7 +18,7 @@ EXPORTS = [
     "wt_plan_create", "wt_plan_destroy", "wt_plan_workspace_bytes", "wt_plan_frames", "wt_plan_num_launches",
     "wt_plan_find_buffer", "wt_plan_buffer_name", "wt_plan_num_steps", "wt_plan_step_name", "wt_plan_set_timing",
     "wt_plan_read_timing", "wt_encode", "wt_codes_to_features", "wt_decode",
-    "wt_seanet_decode", "wt_sconv1d", "wt_linear", "wt_vq_workspace_bytes", "wt_vq_nearest",
+    "wt_seanet_decode", "wt_sconv1d", "wt_linear", "wt_conv1d_s32", "wt_vq_workspace_bytes", "wt_vq_nearest",
 ]
 
 WT_PLAN_ENCODE, WT_PLAN_DECODE, WT_PLAN_SEANET_DECODER = 0, 1, 2
@@ -76,6 +76,8 @@ def _load() -> ctypes.CDLL:
     lib.wt_sconv1d.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32,
                                c_int32, c_int32, c_int32, c_void_p]
     lib.wt_linear.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p]
+    lib.wt_conv1d_s32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32,
+                                  c_int32, c_int32, c_void_p, c_void_p]
     lib.wt_vq_workspace_bytes.argtypes = [c_int64, c_int32]
     lib.wt_vq_workspace_bytes.restype = c_size_t
     lib.wt_vq_nearest.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]

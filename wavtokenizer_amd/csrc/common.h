@@ -74,28 +74,33 @@ struct GemmArgs {
     int*   vq_pidx = nullptr;
     int vq_nparts = 0;
     int group_m = 8;      // tile scheduling group (set by launch_gemm)
+    int dbg = 0;          // gemm16s timing experiments only (WT_GEMM16S_DBG): 1 no DMA in the K loop, 2 no MFMA, 4 no epilogue
 };
 
 int gemm_vq_parts(int N);   // partial (val, idx) slots per row written by EPI_ARGMAX
 int launch_gemm(const GemmArgs& a, int pro, int epi, hipStream_t s);
 int launch_gemm16(const GemmArgs& a, int pro, int epi, hipStream_t s);
 int gemm16_vq_parts(int N);
-int launch_split_f16x2(const float* w, void* hi, void* lo, long n, hipStream_t s);   // weights -> f16 (hi, lo) arrays   // f16x3-split fp32-equivalent GEMM (gemm16.hip)
+int launch_split_f16x2(const float* w, void* hi, void* lo, long n, hipStream_t s);   // weights -> f16 (hi, lo) arrays (gemm16.hip)
+// gemm16s.hip: both operands pre-split in the S32 layout (128-byte groups [32 x f16 hi | 32 x f16 lo], same
+// footprint and strides as the fp32 array); a.A / a.W_hi point at S32 data, out_s32 selects an S32 C
+int launch_gemm16s(const GemmArgs& a, int epi, int out_s32, hipStream_t s);
+int launch_split_s32(const float* x, void* out, long n, hipStream_t s);
 
 // ------------------------------------------------------------------------ non-GEMM kernels
 int launch_conv_first(const float* wav, const float* w /*[7][Cout]*/, const float* bias, float* y, int B, long T,
                       int k, int Cout, hipStream_t s);
 int launch_conv_last(const float* x /*[B][T][Cin]*/, const float* w /*[k][Cin]*/, const float* bias, float* y /*[B][T]*/,
                      int B, long T, int Cin, int k, int elu_in, hipStream_t s);
-int launch_transpose(const float* in, float* out, int B, int R, int C, hipStream_t s);  // [B][R][C] -> [B][C][R]
+int launch_transpose(const float* in, float* out, int B, int R, int C, hipStream_t s, int out_s32 = 0);  // [B][R][C] -> [B][C][R]
 int launch_gn_stats(const float* x, const float* gamma, const float* beta, float* scale, float* shift, int B, int L,
                     int C, int groups, float eps, hipStream_t s);
 int launch_gn_apply(const float* x, const float* gamma, const float* beta, float* scale, float* shift, float* y,
-                    int swish, int B, int L, int C, int groups, float eps, hipStream_t s);
+                    int swish, int B, int L, int C, int groups, float eps, hipStream_t s, int out_s32 = 0);
 enum RowNormMode : int { RN_DWCONV = 0, RN_PLAIN = 1, RN_AFFINE_IN = 2 };
 int launch_rownorm(int mode, const float* x, float* y, int B, int L, int C, const float* dw_w /*[7][C]*/,
                    const float* dw_b, const float* in_scale, const float* in_shift, const float* out_scale,
-                   const float* out_shift, float eps, hipStream_t s);
+                   const float* out_shift, float eps, hipStream_t s, int out_s32 = 0);
 int launch_istft_ola(const float* parts /*[4][M][Kq]*/, const float* win, const float* wsq, float* out, int B, int L,
                      int n_fft, int hop, int Kq, hipStream_t s);
 int launch_softmax(float* S, int rows, int L, int ld, hipStream_t s);

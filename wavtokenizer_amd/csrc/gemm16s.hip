@@ -1,0 +1,505 @@
+// Split-f16 GEMM on PRE-SPLIT operands, staged global -> LDS by LDS-DMA (buffer_load ... lds).
+//
+// Same arithmetic as gemm16.hip (x = hi + lo * 2^-11, three v_mfma_f32_32x32x16_f16 per 16-deep step into a main
+// and a correction accumulator: fp32-equivalent products), but both operands arrive already split, in the
+// "S32" layout: every run of 32 consecutive fp32 elements of a row becomes one 128-byte group
+//      [32 x f16 hi | 32 x f16 lo]
+// so an S32 array has exactly the footprint and the row strides of the fp32 array it stands for, element e of a
+// row starts at byte (e & ~31) * 4 + (e & 31) * 2, and one K step (32 deep) of one row is one full 128-byte line.
+// Producers write S32 directly (norm kernels, the GELU / head epilogues here, weights once at load), so the K loop
+// has no conversion work at all: per step a wave issues a few LDS-DMA loads (8 rows x 128 B each, no VGPRs), 16
+// ds_read_b128 and 18 MFMAs.  The conv gather (taps, stride, reflect / zero padding, ragged edges) is the same
+// per-(tap, row) byte-offset table as gemm.hip; an out-of-range offset makes the DMA write zeros.
+//
+// LDS image of a stage: (BM + BN) rows x 128 B; the eight 16-byte chunks of row r are XOR-swizzled with
+// (r >> 1) & 7, applied on the SOURCE address of the DMA (its LDS side is lane-linear) and on the ds_read address:
+// every ds_read_b128 lane group then covers all 64 banks.
+#include "common.h"
+
+#include <cmath>
+#include <stdlib.h>
+
+namespace wt {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+static constexpr int SBK = 32;          // k elements per step = one 128-byte S32 group per row
+
+__device__ __forceinline__ int xcd_remap_s(int orig, int nwg) {
+    int q = nwg >> 3, r = nwg & 7;
+    int xcd = orig & 7, idx = orig >> 3;
+    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+__device__ __forceinline__ float elu_s(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
+// erf to < 1 ulp (max abs error 6.3e-8 against float64 erf over [-6, 6], checked on the host), branch-free: the
+// two minimax pieces |a| <= 475/512 (odd polynomial) and beyond (1 - exp(polynomial)) are both evaluated and selected
+__device__ __forceinline__ float erf_s(float a) {
+    const float t = fabsf(a), s = a * a;
+    float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+    const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+    r = fmaf(r, s, u);
+    r = fmaf(r, t, -1.06777877e-1f);
+    r = fmaf(r, t, -6.34846687e-1f);
+    r = fmaf(r, t, -1.28717512e-1f);
+    r = fmaf(r, t, -t);
+    const float big = copysignf(1.0f - __expf(r), a);
+    float q = -5.96761703e-4f;
+    q = fmaf(q, s, 4.99119423e-3f);
+    q = fmaf(q, s, -2.67681349e-2f);
+    q = fmaf(q, s, 1.12819925e-1f);
+    q = fmaf(q, s, -3.76125336e-1f);
+    q = fmaf(q, s, 1.28379166e-1f);
+    const float small = fmaf(q, a, a);
+    return t > 0.927734375f ? big : small;
+}
+__device__ __forceinline__ float gelu_erf_s(float x) { return x * 0.5f * (1.f + erf_s(x * 0.70710678118654752440f)); }
+
+// fp32 value -> S32 slots of element n (n & 31 = slot) in the group that starts at `grp` (a _Float16*)
+__device__ __forceinline__ void store_s32(_Float16* grp, int slot, float v) {
+    const _Float16 h = (_Float16)v;
+    grp[slot] = h;
+    grp[32 + slot] = (_Float16)((v - (float)h) * 2048.f);
+}
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+// four consecutive elements n .. n+3 (n % 4 == 0) of a row in S32: 8 bytes of hi halves, 8 bytes of lo halves
+__device__ __forceinline__ void store_s32_x4(float* row, int n, const f32x4 v) {
+    f16x4 hi, lo;
+    hi.x = (_Float16)v.x; hi.y = (_Float16)v.y; hi.z = (_Float16)v.z; hi.w = (_Float16)v.w;
+    lo.x = (_Float16)((v.x - (float)hi.x) * 2048.f); lo.y = (_Float16)((v.y - (float)hi.y) * 2048.f);
+    lo.z = (_Float16)((v.z - (float)hi.z) * 2048.f); lo.w = (_Float16)((v.w - (float)hi.w) * 2048.f);
+    _Float16* g = reinterpret_cast<_Float16*>(row) + ((n >> 5) * 64 + (n & 31));
+    *reinterpret_cast<f16x4*>(g) = hi;
+    *reinterpret_cast<f16x4*>(g + 32) = lo;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm_lgkm() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int EPI, int OUT_S32>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(const GemmArgs p) {
+    constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int STG = (BM + BN) * 128;                   // bytes per stage
+    constexpr int NPA = BM / 8 / NW, NPB = BN / 8 / NW;    // DMA pieces (8 rows x 128 B) per wave and K step
+    constexpr int NPT = NPA + NPB;
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "pieces must divide evenly among the waves");
+    static_assert(WM % 32 == 0 && WN % 32 == 0 && BM % 16 == 0, "32x32 MFMA tiles");
+    static_assert((NSTAGE - 2) * NPT < 64, "vmcnt field");
+    extern __shared__ __attribute__((aligned(1024))) char smem_s[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int ntiles = tiles_m * tiles_n;
+    const int G = gridDim.x;                 // persistent: this workgroup owns tiles blockIdx.x, + G, + 2G, ...
+    const int z = blockIdx.z;
+    const int nclips = p.M / p.T_out;
+    constexpr unsigned OOB = 0x80000000u;
+
+    // virtual block -> (row tile, column tile): XCD-contiguous, then grouped GM row tiles at a time (gemm.hip)
+    auto tile_coords = [&](int vb, int& bm, int& bn) {
+        const int tile = xcd_remap_s(vb, ntiles);
+        const int per_group = p.group_m * tiles_n;
+        const int grp = tile / per_group;
+        const int first_m = grp * p.group_m;
+        const int gsz = tiles_m - first_m < p.group_m ? tiles_m - first_m : p.group_m;
+        const int in_grp = tile - grp * per_group;
+        bm = first_m + in_grp % gsz;
+        bn = in_grp / gsz;
+    };
+    auto first_clip = [&](int bm) { return (bm * BM < p.M ? bm * BM : p.M - 1) / p.T_out; };
+
+    // S32 arrays are addressed in bytes = 4 x the fp32 element offset
+    const char* Ag = reinterpret_cast<const char*>(p.A) + (long)z * p.zA * 4;
+    const char* Wg = reinterpret_cast<const char*>(p.W_hi) + (long)z * p.zW * 4;
+    const long w_span = (long)p.N * p.w_rstride * 4;
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(Wg), 0, (int)(w_span < 0x7fffffffL ? w_span : 0x7fffffffL), 0x00020000);
+
+    // two [taps][BM] tables of per-(tap, row) byte offsets: the tile being loaded and the one after it
+    unsigned* s_rowoff = reinterpret_cast<unsigned*>(smem_s + NSTAGE * STG);
+    const int tab_sz = p.taps * BM;
+    auto build_table = [&](int vb, int par) {
+        if (vb >= ntiles) return;
+        int bm, bn;
+        tile_coords(vb, bm, bn);
+        const int clip0 = first_clip(bm);
+        unsigned* tab = s_rowoff + par * tab_sz;
+        for (int e = tid; e < tab_sz; e += NT) {
+            const int tp = e / BM, r = e - tp * BM;
+            const int m = bm * BM + r;
+            unsigned off = OOB;
+            if (m < p.M) {
+                const int b = m / p.T_out;
+                const int t = m - b * p.T_out;
+                int pos = t * p.stride - p.pad_left + tp * p.dil;
+                bool ok;
+                if (p.pad_mode == PAD_REFLECT) {
+                    pos = pos < 0 ? -pos : pos;
+                    pos = pos >= p.Tp ? 2 * (p.Tp - 1) - pos : pos;
+                    ok = pos < p.T_in;
+                } else {
+                    ok = (pos >= 0) && (pos < p.T_in);
+                }
+                if (ok) off = (unsigned)(((long)(b - clip0) * p.a_bstride + (long)pos * p.a_rstride) * 4);
+            }
+            tab[e] = off;
+        }
+    };
+
+    // ---- loader: a continuous stream of K tiles that runs NSTAGE-1 steps ahead of the MFMAs and crosses from one
+    // output tile into the next without a seam.  DMA piece q = 8 image rows; lane -> (row q*8 + lane/8, physical
+    // chunk lane%8); the logical chunk it must fetch is physical ^ ((row >> 1) & 7)
+    const int prow = lane >> 3;
+    int a_row[NPA];
+    unsigned a_chunk[NPA], w_chunk[NPB];
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+        const int q = wave + NW * i;
+        a_row[i] = q * 8 + prow;
+        a_chunk[i] = (unsigned)(((lane & 7) ^ (((q & 1) << 2) | (lane >> 4))) * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < NPB; ++j) {
+        const int q = BM / 8 + wave + NW * j;
+        w_chunk[j] = (unsigned)(((lane & 7) ^ (((q & 1) << 2) | (lane >> 4))) * 16);
+    }
+    unsigned a_voff[NPA], w_voff[NPB];
+    __amdgpu_buffer_rsrc_t rsA;
+    int l_vb = blockIdx.x, l_par = 0, tapL = 0, ciL = 0, kL = 0;
+    unsigned l_mask = 0;
+    auto set_tap = [&](int tap) {
+        const unsigned* tab = s_rowoff + l_par * tab_sz;
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) a_voff[i] = tab[tap * BM + a_row[i]] + a_chunk[i];
+    };
+    auto loader_set_tile = [&](int vb, int par) {       // the table of `vb` (parity par) must be visible
+        l_vb = vb; l_par = par; tapL = 0; ciL = 0; kL = 0;
+        if (vb >= ntiles) { l_mask = OOB; return; }
+        int bm, bn;
+        tile_coords(vb, bm, bn);
+        const int clip0 = first_clip(bm);
+        const char* Ablk = Ag + (long)clip0 * p.a_bstride * 4;
+        const long a_span = ((long)(nclips - clip0 - 1) * p.a_bstride + (long)p.T_in * p.a_rstride) * 4;
+        rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Ablk), 0,
+                                                (int)(a_span < 0x7fffffffL ? a_span : 0x7fffffffL), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NPB; ++j) {
+            const int n = bn * BN + (wave + NW * j) * 8 + prow;
+            w_voff[j] = n < p.N ? (unsigned)((long)n * p.w_rstride * 4) + w_chunk[j] : OOB;
+        }
+        set_tap(0);
+    };
+    auto load_tile = [&](int stage) {
+        const unsigned kadvA = (unsigned)ciL * 4u, kadvW = (unsigned)kL * 4u;
+        char* sbase = smem_s + stage * STG + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < NPA; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(sbase + NW * i * 1024), 16,
+                                                     (int)((a_voff[i] | l_mask) + kadvA), 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NPB; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(sbase + (BM / 8 + NW * j) * 1024), 16,
+                                                     (int)((w_voff[j] | l_mask) + kadvW), 0, 0, 0);
+        kL += SBK; ciL += SBK;
+        if (kL >= p.K) {
+            if (l_mask == 0) loader_set_tile(l_vb + G, l_par ^ 1);     // on into the next output tile
+        } else if (p.taps > 1 && ciL >= p.Cin) {
+            ciL = 0; ++tapL; set_tap(tapL);
+        }
+    };
+
+    // fragment (v_mfma_f32_32x32x16_f16): lane (r = lane & 31, h = lane >> 5) holds k = 16 s + 8 h .. + 7 of row r:
+    // logical chunk 2 s + h of the hi half, 4 + 2 s + h of the lo half
+    const int frow = (lane & 31) * 128, fsw = ((lane & 31) >> 1) & 7, fh = lane >> 5;
+    int fo[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) fo[c] = frow + (((2 * c + fh) ^ fsw) * 16);
+    const int offA = wm * WM * 128, offB = (BM + wn * WN) * 128;
+
+    // Operand order: the weight fragment is the MFMA's A operand and the activation fragment its B operand, so the
+    // accumulator comes out transposed: lane -> output ROW (m = lane & 31), registers -> 4-column runs
+    // n = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  The epilogue then moves 16 bytes (fp32) or 8 + 8 bytes (S32) per
+    // lane and store, and bias / gamma are per-register vectors.
+    f32x16 accm[TM][TN], accc[TM][TN];
+    struct Frags { f16x8 ah[TM], al[TM], bh[TN], bl[TN]; };
+    auto read_frags = [&](int stage, int s, Frags& F) {
+        const char* sA = smem_s + stage * STG + offA;
+        const char* sB = smem_s + stage * STG + offB;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            F.ah[i] = *reinterpret_cast<const f16x8*>(sA + i * 32 * 128 + fo[s]);
+            F.al[i] = *reinterpret_cast<const f16x8*>(sA + i * 32 * 128 + fo[2 + s]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            F.bh[j] = *reinterpret_cast<const f16x8*>(sB + j * 32 * 128 + fo[s]);
+            F.bl[j] = *reinterpret_cast<const f16x8*>(sB + j * 32 * 128 + fo[2 + s]);
+        }
+    };
+    auto mfma_block = [&](const Frags& F) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.bh[j], F.ah[i], accm[i][j], 0, 0, 0);
+                accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.bl[j], F.ah[i], accc[i][j], 0, 0, 0);
+                accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.bh[j], F.al[i], accc[i][j], 0, 0, 0);
+            }
+    };
+
+    // NSTAGE-deep ring of LDS stages, ONE barrier per K step, placed in the MIDDLE of the step:
+    //   top    : DMA of the K tile NSTAGE-1 steps ahead -> the stage the previous step's tile occupied (all its reads
+    //            retired before the previous barrier); read the second-half fragments of this step's tile; MFMAs on
+    //            its first half (already in registers)
+    //   middle : each wave waits for ITS OWN pieces of the next K tile (counted vmcnt: younger tiles stay in flight)
+    //            and for its LDS reads, then the barrier makes that tile visible to everyone
+    //   bottom : read the first-half fragments of the next K tile, MFMAs on the second half of this one
+    // so no wave sits behind a barrier with nothing to issue: fragments always arrive under the other half's MFMAs.
+    // The stream does not stop at an output-tile boundary: the first K tiles of the workgroup's next output tile are
+    // already landing while the last steps of this one run, its first fragments are read before the epilogue, and
+    // the epilogue's own loads and stores simply queue behind them.  Past the last tile the DMAs are issued all the
+    // same with out-of-range offsets (constant wait counts).
+    const int nk = p.K / SBK;
+    build_table(blockIdx.x, 0);
+    __syncthreads();
+    loader_set_tile(blockIdx.x, 0);
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s) load_tile(s);       // needs nk >= NSTAGE - 1 when a next tile exists (host)
+    wait_vm_lgkm<(NSTAGE - 2) * NPT>();
+    __builtin_amdgcn_s_barrier();
+    Frags F0, F1;
+    read_frags(0, 0, F0);
+    int rs = 0, ws = NSTAGE - 1;
+    int c_par = 0;
+    for (int vb = blockIdx.x; vb < ntiles; vb += G, c_par ^= 1) {
+        // the table of this workgroup's next output tile: the loader turns to it NSTAGE-1 steps before this tile's
+        // K loop ends, i.e. after at least one of the barriers below (host: nk >= NSTAGE + 1 in persistent launches)
+        build_table(vb + G, c_par ^ 1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { accm[i][j][r] = 0.f; accc[i][j][r] = 0.f; }
+        for (int kt = 0; kt < nk; ++kt) {
+            if (!(p.dbg & 1)) load_tile(ws);
+            if (!(p.dbg & 16)) read_frags(rs, 1, F1);
+            if (!(p.dbg & 2)) mfma_block(F0);
+            if (!(p.dbg & 32)) wait_vm_lgkm<(NSTAGE - 2) * NPT>();
+            if (!(p.dbg & 8)) __builtin_amdgcn_s_barrier();
+            rs = rs + 1 == NSTAGE ? 0 : rs + 1;
+            ws = ws + 1 == NSTAGE ? 0 : ws + 1;
+            if (!(p.dbg & 16)) read_frags(rs, 0, F0);          // after the very last step: a harmless read of a zero-filled stage
+            if (!(p.dbg & 2)) mfma_block(F1);
+        }
+        if (p.dbg & 4) continue;
+        int bm, bn;
+        tile_coords(vb, bm, bn);
+
+    // ------------------------------------------------------------------------- epilogue
+    const int row_l = lane & 31, col_h = 4 * (lane >> 5);
+    const int m_w = bm * BM + wm * WM, n_w = bn * BN + wn * WN;
+    float* __restrict__ Cg = p.C + (long)z * p.zC;
+    constexpr float LO_SCALE = 1.f / 2048.f;
+    auto acc4 = [&](int i, int j, int g) {
+        f32x4 v;
+        v.x = accm[i][j][4 * g + 0] + accc[i][j][4 * g + 0] * LO_SCALE;
+        v.y = accm[i][j][4 * g + 1] + accc[i][j][4 * g + 1] * LO_SCALE;
+        v.z = accm[i][j][4 * g + 2] + accc[i][j][4 * g + 2] * LO_SCALE;
+        v.w = accm[i][j][4 * g + 3] + accc[i][j][4 * g + 3] * LO_SCALE;
+        return v;
+    };
+
+    if constexpr (EPI == EPI_HEAD) {
+        static_assert(TN % 2 == 0, "head epilogue pairs column tiles");
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m_w + i * 32 + row_l;
+            if (m >= p.M) continue;
+            float* crow = Cg + (long)m * p.c_rstride;
+#pragma unroll
+            for (int j = 0; j + 1 < TN; j += 2)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int pc = n_w + j * 32 + 8 * g + col_h;      // packed row of the log-magnitude; phase 32 later
+                    if (pc >= p.N) continue;
+                    const f32x4 bmag = *reinterpret_cast<const f32x4*>(p.bias + pc);
+                    const f32x4 bph = *reinterpret_cast<const f32x4*>(p.bias + pc + 32);
+                    const f32x4 lm = acc4(i, j, g) + bmag, ph = acc4(i, j + 1, g) + bph;
+                    f32x4 re, im;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float mag = fminf(expf(lm[e]), 100.f);                 // heads.py:55-56
+                        re[e] = mag * cosf(ph[e]);
+                        im[e] = mag * sinf(ph[e]);
+                    }
+                    const int f = (pc >> 6) * 32 + (pc & 31);          // bin slot
+                    if (OUT_S32) {
+                        store_s32_x4(crow, f, re);
+                        store_s32_x4(crow, p.head_kb + f, im);
+                    } else {
+                        *reinterpret_cast<f32x4*>(crow + f) = re;
+                        *reinterpret_cast<f32x4*>(crow + p.head_kb + f) = im;
+                    }
+                }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m_w + i * 32 + row_l;
+            if (m >= p.M) continue;
+            float* crow = Cg + (long)m * p.c_rstride;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n_w + j * 32 + 8 * g + col_h;        // columns n .. n+3 (N % 4 == 0)
+                    if (n >= p.N) continue;
+                    f32x4 v = acc4(i, j, g);
+                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                    if (EPI == EPI_BIAS_RES) {
+                        v = v + *reinterpret_cast<const f32x4*>(p.R + (long)m * p.r_rstride + n);
+                    } else if (EPI == EPI_BIAS_RES_ELU) {
+                        v = v + *reinterpret_cast<const f32x4*>(p.R + (long)m * p.r_rstride + n);
+                        v.x = elu_s(v.x); v.y = elu_s(v.y); v.z = elu_s(v.z); v.w = elu_s(v.w);
+                    } else if (EPI == EPI_BIAS_GELU) {
+                        v.x = gelu_erf_s(v.x); v.y = gelu_erf_s(v.y); v.z = gelu_erf_s(v.z); v.w = gelu_erf_s(v.w);
+                    } else if (EPI == EPI_BIAS_GAMMA_RES) {
+                        const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + n);
+                        v = *reinterpret_cast<const f32x4*>(p.R + (long)m * p.r_rstride + n) + gm * v;
+                    }
+                    if (OUT_S32) store_s32_x4(crow, n, v);
+                    else *reinterpret_cast<f32x4*>(crow + n) = v;
+                }
+        }
+    }
+    }   // persistent tile loop
+    wait_vm_lgkm<0>();
+}
+
+// fp32 -> S32 (flat: rows are multiples of 32 elements, so the layout is a function of the flat index alone)
+__global__ __launch_bounds__(256) void split_s32_kernel(const float* __restrict__ x, _Float16* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        const _Float16 h = (_Float16)v;
+        const long g = (i >> 5) * 64 + (i & 31);
+        out[g] = h;
+        out[g + 32] = (_Float16)((v - (float)h) * 2048.f);
+    }
+}
+
+int launch_split_s32(const float* x, void* out, long n, hipStream_t s) {
+    if (n % 32) { set_error("split_s32: element count must be a multiple of 32"); return -1; }
+    int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(split_s32_kernel, dim3(blocks), dim3(256), 0, s, x, static_cast<_Float16*>(out), n);
+    WT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------- host side
+template <int BM, int BN, int WMs, int WNs, int NSTAGE, int EPI, int OUT_S32>
+static int launch16s_one(const GemmArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    constexpr size_t stage_bytes = (size_t)NSTAGE * (BM + BN) * 128;
+    const size_t smem = stage_bytes + 2ull * a.taps * BM * sizeof(unsigned);
+    constexpr size_t smem_cap = 160 * 1024;
+    constexpr size_t smem_want = stage_bytes + 2ull * 32 * BM * sizeof(unsigned);
+    constexpr size_t smem_max = smem_want < smem_cap ? smem_want : smem_cap;
+    static_assert(stage_bytes + 2 * BM * sizeof(unsigned) <= smem_cap, "LDS budget");
+    if (smem > smem_cap) { set_error("gemm16s: too many taps for this tile's LDS budget"); return -1; }
+    auto kern = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT_S32>;
+    if (!attr_set) {
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)smem_max));
+        attr_set = true;
+    }
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+    const int ntiles = tiles_m * tiles_n;
+    // Persistent launch: one workgroup per slot (256 CUs x resident workgroups per CU), each walking tiles
+    // b, b + G, ... with its loader streaming across the seams.  The slot count must stay a multiple of 8 so that a
+    // workgroup's tiles stay on its XCD, and K must be deep enough for the table hand-over (see the kernel).
+    const int per_cu = (WMs * WNs <= 4 && smem * 2 <= smem_cap) ? 2 : 1;
+    int G = (256 * per_cu / a.nz) & ~7;
+    const char* np = getenv("WT_GEMM16S_NONPERSISTENT");
+    if (G < 8 || ntiles <= G || a.K / SBK < NSTAGE + 1 || (np && np[0] == '1')) G = ntiles;
+    GemmArgs b = a;
+    if (const char* e = getenv("WT_GEMM16S_DBG")) b.dbg = atoi(e);
+    hipLaunchKernelGGL(kern, dim3(G, 1, a.nz), dim3(64 * WMs * WNs), smem, s, b);
+    WT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static int tile16s_override() {
+    const char* e = getenv("WT_GEMM16S_TILE");      // read per launch: tools/gemm16s_bench.py switches it in-process
+    return e ? atoi(e) : -1;
+}
+
+template <int EPI, int OUT_S32>
+static int launch16s_tiled(const GemmArgs& a, hipStream_t s) {
+    if constexpr (EPI == EPI_HEAD) {
+        return launch16s_one<128, 128, 4, 2, 3, EPI, OUT_S32>(a, s);      // wave tile 32x64: paired column tiles
+    } else {
+        switch (tile16s_override()) {       // experiment hook (tools/linear_bench.py)
+            case 1: return launch16s_one<128, 96, 4, 1, 2, EPI, OUT_S32>(a, s);
+            case 2: return launch16s_one<128, 192, 4, 2, 3, EPI, OUT_S32>(a, s);
+            case 3: return launch16s_one<128, 128, 4, 2, 3, EPI, OUT_S32>(a, s);
+            case 5: return launch16s_one<128, 128, 4, 2, 4, EPI, OUT_S32>(a, s);
+            case 6: return launch16s_one<128, 192, 4, 2, 2, EPI, OUT_S32>(a, s);
+            case 7: return launch16s_one<256, 128, 4, 2, 3, EPI, OUT_S32>(a, s);
+            default: break;
+        }
+        // one 8-wave workgroup per CU (256 slots): 128x192 unless its last round would be mostly idle
+        const long tm = (a.M + 127) / 128;
+        auto cost = [&](int bn, double eff) {
+            const long t = tm * ((a.N + bn - 1) / bn) * a.nz;
+            return std::ceil((double)t / 256.0) * bn / eff;
+        };
+        if (cost(128, 0.92) < cost(192, 1.0)) return launch16s_one<128, 128, 4, 2, 3, EPI, OUT_S32>(a, s);
+        return launch16s_one<128, 192, 4, 2, 3, EPI, OUT_S32>(a, s);
+    }
+}
+
+// Contract of launch_gemm16 with both operands in S32: a.A = S32 activations (same strides as the fp32 array),
+// a.W_hi = S32 weights [N][K]; out_s32 selects an S32 C (c_rstride in fp32 elements either way).
+int launch_gemm16s(const GemmArgs& a_in, int epi, int out_s32, hipStream_t s) {
+    const GemmArgs& c = a_in;
+    if (c.M <= 0 || c.N <= 0 || c.K <= 0 || c.K % SBK || c.Cin % SBK || c.K != c.taps * c.Cin || c.T_out <= 0 ||
+        c.M % c.T_out || c.taps > 32 || !c.W_hi || !c.A || (c.w_rstride % 32) || (c.zW % 32) || (c.a_rstride % 32) ||
+        (c.a_bstride % 32) || (c.zA % 32) || (c.N % 4) || (c.c_rstride % 4) || (c.zC % 4) || (c.r_rstride % 4) || (out_s32 && ((c.c_rstride % 32) || (c.zC % 32) || (c.N % 32)))) {
+        set_error("gemm16s: unsupported problem (S32 operands need every extent and stride in multiples of 32)");
+        return -1;
+    }
+    if ((reinterpret_cast<uintptr_t>(c.A) & 127) || (reinterpret_cast<uintptr_t>(c.W_hi) & 127)) {
+        set_error("gemm16s: S32 operands must be 128-byte aligned"); return -1;
+    }
+    {
+        const long clips_per_tile = 256 / c.T_out + 2;
+        if ((clips_per_tile * c.a_bstride + (long)c.T_in * c.a_rstride) * 4 >= 0x40000000L ||
+            (long)c.N * c.w_rstride * 4 >= 0x40000000L) {
+            set_error("gemm16s: operand window exceeds the 1 GiB buffer-offset range"); return -1;
+        }
+    }
+    if (c.pad_mode == PAD_REFLECT && c.Tp < c.T_in) { set_error("gemm16s: reflect Tp < T_in"); return -1; }
+    GemmArgs a = a_in;
+    a.group_m = (a.N + 191) / 192 > 8 ? 8 : 1;
+#define WT_CASE16S(E, O) if (epi == E && out_s32 == O) return launch16s_tiled<E, O>(a, s);
+    WT_CASE16S(EPI_BIAS, 0)
+    WT_CASE16S(EPI_BIAS, 1)
+    WT_CASE16S(EPI_BIAS_RES, 0)
+    WT_CASE16S(EPI_BIAS_GELU, 1)
+    WT_CASE16S(EPI_BIAS_GAMMA_RES, 0)
+    WT_CASE16S(EPI_HEAD, 1)
+#undef WT_CASE16S
+    set_error("gemm16s: unsupported epilogue / output-format pair");
+    return -1;
+}
+
+}  // namespace wt

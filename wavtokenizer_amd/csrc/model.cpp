@@ -66,6 +66,9 @@ struct wt_model {
     // fp32 device pointer the plans already use; `lo_off` = elements between the hi and the lo array
     struct Split16 { void* hi; long lo_off; };
     std::map<const float*, Split16> split16;
+    // S32 copies (gemm16s.hip: 128-byte groups [32 x f16 hi | 32 x f16 lo], same footprint as fp32) of the weights
+    // whose GEMMs take pre-split activations, keyed the same way
+    std::map<const float*, void*> s32;
     // encoder
     float *e0_w = nullptr, *e0_b = nullptr;   // [7][32], [32]
     int e0_k = 7, e0_c = 32;
@@ -448,10 +451,33 @@ static int add_split(wt_model* M, const float* w, long n) {
     return 0;
 }
 
+static int add_s32(wt_model* M, const float* w, long n) {
+    if (!w || n <= 0 || (n % 32)) return 0;
+    void* d = nullptr;
+    WT_HIP_CHECK(hipMalloc(&d, (size_t)n * 4));
+    M->allocs.push_back(d);
+    M->weight_bytes += n * 4;
+    if (int rc = launch_split_s32(w, d, n, nullptr)) return rc;
+    M->s32[w] = d;
+    return 0;
+}
+
 static int build_splits(wt_model* M) {
     const wt_arch& a = M->arch;
     const int D = a.dim, I = a.intermediate_dim;
     auto conv = [&](const ConvW& c) { return add_split(M, c.w, (long)c.cout * c.k * c.cin); };
+    auto conv32 = [&](const ConvW& c) { return (c.cin % 32) ? 0 : add_s32(M, c.w, (long)c.cout * c.k * c.cin); };
+    if (int rc = conv32(M->bb_embed)) return rc;
+    for (int i = 0; i < 4; ++i) {
+        if (int rc = conv32(M->res[i].c1)) return rc;
+        if (int rc = conv32(M->res[i].c2)) return rc;
+    }
+    for (const CnxBlock& c : M->cnx) {
+        if (int rc = add_s32(M, c.W1, (long)I * D)) return rc;
+        if (int rc = add_s32(M, c.W2, (long)D * I)) return rc;
+    }
+    if (int rc = add_s32(M, M->head_W, 2L * M->Kb * D)) return rc;
+    if (int rc = add_s32(M, M->istft_W, 4L * M->Kq * M->Kq)) return rc;
     for (const ResStage& st : M->stages) {
         if (int rc = conv(st.down)) return rc;
         if (int rc = conv(st.sc)) return rc;
@@ -596,6 +622,17 @@ static int gemm_auto(const wt_plan* P, const GemmArgs& a, int pro, int epi, hipS
     }
     return launch_gemm(a, pro, epi, s);
 }
+
+// Both operands pre-split (S32): the activations were written in S32 by their producer, the weight has an S32 copy
+static int gemm_s32(const wt_plan* P, const GemmArgs& a, int epi, int out_s32, hipStream_t s) {
+    auto it = P->model->s32.find(a.W);
+    if (it == P->model->s32.end()) { set_error("internal: no S32 copy of this weight"); return WT_ERR_INVALID; }
+    GemmArgs b = a;
+    b.W_hi = it->second;
+    return launch_gemm16s(b, epi, out_s32, s);
+}
+// The decoder's dense chain runs on S32 operands unless stage taps are kept (fp32 taps) or fp32 GEMMs are forced
+static bool plan_s32(const wt_plan* P) { return !(P->flags & (WT_PLAN_FLAG_KEEP_STAGES | WT_PLAN_FLAG_FP32_GEMM)); }
 
 // SConv1d geometry (encoder/modules/conv.py:195-211, 54-61), non-causal.
 struct SConvGeom { int pl, pr_total, Tout, Tp; };
@@ -791,12 +828,16 @@ static int build_decode(wt_plan* P) {
     const int B = P->B, L = (int)P->L, D = ar.dim, I = ar.intermediate_dim, Cin = ar.input_channels;
     const long Mrows = (long)B * L;
     const int Lp = ((L + 31) / 32) * 32;
+    // S32 mode: every operand of the dense chain is written pre-split by its producer (transpose, norm kernels,
+    // GELU / head epilogues) and multiplied by gemm16s.hip; the residual stream and the norm inputs stay fp32
+    const bool s32 = plan_s32(P) && (Cin % 32 == 0) && (D % 32 == 0) && (I % 32 == 0);
     const int x0 = P->buf("bb.in", (size_t)Mrows * Cin);
-    P->step({x0}, [=](const RunCtx& c) { return launch_transpose(c.in_f, P->ptr(c, x0), B, Cin, L, c.stream); });
+    P->step({x0}, [=](const RunCtx& c) { return launch_transpose(c.in_f, P->ptr(c, x0), B, Cin, L, c.stream, s32); });
     const int x = P->buf("bb.x", (size_t)Mrows * D);       // residual stream, updated in place
     GemmArgs ae = zconv_args(M->bb_embed, B, L);
     P->step({x0, x}, [=](const RunCtx& c) {
         GemmArgs a = ae; a.A = P->ptr(c, x0); a.C = P->ptr(c, x);
+        if (s32) return gemm_s32(P, a, EPI_BIAS, 0, c.stream);
         return gemm_auto(P, a, PRO_NONE, EPI_BIAS, c.stream);
     });
     const bool keep = P->flags & WT_PLAN_FLAG_KEEP_STAGES;
@@ -818,19 +859,21 @@ static int build_decode(wt_plan* P) {
     // where every element would be re-normalised by each of the 18 (tap, column-tile) re-reads.
     auto resnet = [&](const PosRes& r, const std::string& name) {
         P->step({x, sc, sh, h1}, [=](const RunCtx& c) {
-            return launch_gn_apply(P->ptr(c, x), r.n1w, r.n1b, P->ptr(c, sc), P->ptr(c, sh), P->ptr(c, h1), 1, B, L, D, 32, 1e-6f, c.stream);
+            return launch_gn_apply(P->ptr(c, x), r.n1w, r.n1b, P->ptr(c, sc), P->ptr(c, sh), P->ptr(c, h1), 1, B, L, D, 32, 1e-6f, c.stream, s32);
         }, 1, "res.gn1");
         GemmArgs a1 = zconv_args(r.c1, B, L);
         P->step({h1, h2}, [=](const RunCtx& c) {
             GemmArgs a = a1; a.A = P->ptr(c, h1); a.C = P->ptr(c, h2);
+            if (s32) return gemm_s32(P, a, EPI_BIAS, 0, c.stream);
             return gemm_auto(P, a, PRO_NONE, EPI_BIAS, c.stream);
         }, 1, "res.conv1");
         P->step({h2, sc, sh, h1}, [=](const RunCtx& c) {
-            return launch_gn_apply(P->ptr(c, h2), r.n2w, r.n2b, P->ptr(c, sc), P->ptr(c, sh), P->ptr(c, h1), 1, B, L, D, 32, 1e-6f, c.stream);
+            return launch_gn_apply(P->ptr(c, h2), r.n2w, r.n2b, P->ptr(c, sc), P->ptr(c, sh), P->ptr(c, h1), 1, B, L, D, 32, 1e-6f, c.stream, s32);
         }, 1, "res.gn2");
         GemmArgs a2 = zconv_args(r.c2, B, L);
         P->step({h1, x}, [=](const RunCtx& c) {
             GemmArgs a = a2; a.A = P->ptr(c, h1); a.C = P->ptr(c, x); a.R = P->ptr(c, x); a.r_rstride = D;
+            if (s32) return gemm_s32(P, a, EPI_BIAS_RES, 0, c.stream);
             return gemm_auto(P, a, PRO_NONE, EPI_BIAS_RES, c.stream);
         }, 1, "res.conv2");
         snapshot(name);
@@ -904,16 +947,18 @@ static int build_decode(wt_plan* P) {
         const CnxBlock cb = M->cnx[i];
         P->step({xc, nrm}, [=](const RunCtx& c) {
             return launch_rownorm(RN_DWCONV, P->ptr(c, xc), P->ptr(c, nrm), B, L, D, cb.dw_w, cb.dw_b, nullptr, nullptr,
-                                  cb.ada_s + (size_t)c.bw_id * D, cb.ada_h + (size_t)c.bw_id * D, 1e-6f, c.stream);
+                                  cb.ada_s + (size_t)c.bw_id * D, cb.ada_h + (size_t)c.bw_id * D, 1e-6f, c.stream, s32);
         });
         GemmArgs a1 = linear_args(cb.W1, cb.b1, Mrows, I, D);
         P->step({nrm, mid}, [=](const RunCtx& c) {
             GemmArgs a = a1; a.A = P->ptr(c, nrm); a.C = P->ptr(c, mid);
+            if (s32) return gemm_s32(P, a, EPI_BIAS_GELU, 1, c.stream);       // GELU output pre-split for pwconv2
             return gemm_auto(P, a, PRO_NONE, EPI_BIAS_GELU, c.stream);
         }, 1, "cnx.pwconv1");
         GemmArgs a2 = linear_args(cb.W2, cb.b2, Mrows, D, I);
         P->step({mid, xc}, [=](const RunCtx& c) {
             GemmArgs a = a2; a.A = P->ptr(c, mid); a.C = P->ptr(c, xc); a.R = P->ptr(c, xc); a.r_rstride = D; a.gamma = cb.gamma;
+            if (s32) return gemm_s32(P, a, EPI_BIAS_GAMMA_RES, 0, c.stream);
             return gemm_auto(P, a, PRO_NONE, EPI_BIAS_GAMMA_RES, c.stream);
         }, 1, "cnx.pwconv2");
         if (keep && (i == 0 || i == ar.num_layers / 2 - 1 || i == ar.num_layers - 1)) {
@@ -927,7 +972,10 @@ static int build_decode(wt_plan* P) {
     const int xo = P->buf("bb.out", (size_t)Mrows * D);
     P->step({xc, xo}, [=](const RunCtx& c) {
         if (int rc = launch_rownorm(RN_PLAIN, P->ptr(c, xc), P->ptr(c, xo), B, L, D, nullptr, nullptr, nullptr, nullptr,
-                                    M->fln_w, M->fln_b, 1e-6f, c.stream)) return rc;
+                                    M->fln_w, M->fln_b, 1e-6f, c.stream, s32)) return rc;
+        if (c.aux && s32)      // the caller wants the backbone output: a second, fp32 pass straight into its buffer
+            return launch_rownorm(RN_PLAIN, P->ptr(c, xc), c.aux, B, L, D, nullptr, nullptr, nullptr, nullptr, M->fln_w,
+                                  M->fln_b, 1e-6f, c.stream, 0);
         if (c.aux) WT_HIP_CHECK(hipMemcpyAsync(c.aux, P->ptr(c, xo), (size_t)Mrows * D * sizeof(float), hipMemcpyDeviceToDevice, c.stream));
         return 0;
     });
@@ -937,6 +985,7 @@ static int build_decode(wt_plan* P) {
     GemmArgs ah = linear_args(M->head_W, M->head_b, Mrows, 2 * Kb, D);
     P->step({xo, spec}, [=](const RunCtx& c) {
         GemmArgs a = ah; a.A = P->ptr(c, xo); a.C = P->ptr(c, spec); a.c_rstride = 2 * Kb; a.head_kb = Kb;
+        if (s32) return gemm_s32(P, a, EPI_HEAD, 1, c.stream);                // spectrum pre-split for the ISTFT GEMM
         return gemm_auto(P, a, PRO_NONE, EPI_HEAD, c.stream);
     }, 1, "head.out");
     // ISTFT (spectral_ops.py:56-73): four quarter-size real transforms as one batched GEMM, then the
@@ -948,6 +997,7 @@ static int build_decode(wt_plan* P) {
         a.A = P->ptr(c, spec); a.a_rstride = 2 * Kb; a.zA = Kq;              // z picks the spectrum quarter
         a.zW = (long)Kq * Kq; a.nz = 4;
         a.C = P->ptr(c, parts); a.c_rstride = Kq; a.zC = (long)Mrows * Kq;
+        if (s32) return gemm_s32(P, a, EPI_BIAS, 0, c.stream);
         return gemm_auto(P, a, PRO_NONE, EPI_BIAS, c.stream);
     }, 1, "head.istft");
     P->step({parts}, [=](const RunCtx& c) {
@@ -1216,11 +1266,32 @@ int wt_linear(const float* x, const float* w, const float* bias, float* y, int64
     GemmArgs a = linear_args(w, bias, M, N, K);
     a.A = x; a.C = y;
     if (!f16x3) return launch_gemm(a, PRO_NONE, EPI_BIAS, s);
-    if (!workspace) { set_error("wt_linear: the f16x3 mode needs a workspace of 4*N*K bytes"); return WT_ERR_INVALID; }
+    if (!workspace) { set_error("wt_linear: the f16x3 modes need a workspace"); return WT_ERR_INVALID; }
     char* hi = static_cast<char*>(workspace);
-    if (int rc = launch_split_f16x2(w, hi, hi + (size_t)N * K * 2, (long)N * K, s)) return rc;
-    a.W_hi = hi; a.w_lo_off = (long)N * K;
-    return launch_gemm16(a, PRO_NONE, EPI_BIAS, s);
+    if (f16x3 == 1) {
+        if (int rc = launch_split_f16x2(w, hi, hi + (size_t)N * K * 2, (long)N * K, s)) return rc;
+        a.W_hi = hi; a.w_lo_off = (long)N * K;
+        return launch_gemm16(a, PRO_NONE, EPI_BIAS, s);
+    }
+    char* xs = hi + (size_t)N * K * 4;
+    if (int rc = launch_split_s32(w, hi, (long)N * K, s)) return rc;
+    if (int rc = launch_split_s32(x, xs, (long)M * K, s)) return rc;
+    a.W_hi = hi; a.A = reinterpret_cast<const float*>(xs);
+    return launch_gemm16s(a, EPI_BIAS, f16x3 == 3 ? 1 : 0, s);
+}
+
+int wt_conv1d_s32(const float* x, const float* w, const float* bias, float* y, int32_t B, int64_t T, int32_t Cin,
+                  int32_t Cout, int32_t k, int32_t stride, int32_t zero_same, void* workspace, void* stream) {
+    if (!x || !w || !y || !workspace) { set_error("wt_conv1d_s32: null argument"); return WT_ERR_INVALID; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ConvW cw; cw.w = const_cast<float*>(w); cw.b = const_cast<float*>(bias); cw.cout = Cout; cw.cin = Cin; cw.k = k;
+    GemmArgs a = zero_same ? zconv_args(cw, B, (int)T) : sconv_args(cw, B, T, stride, 1);
+    char* ws = static_cast<char*>(workspace);
+    char* xs = ws + (size_t)Cout * k * Cin * 4;
+    if (int rc = launch_split_s32(w, ws, (long)Cout * k * Cin, s)) return rc;
+    if (int rc = launch_split_s32(x, xs, (long)B * T * Cin, s)) return rc;
+    a.W_hi = ws; a.A = reinterpret_cast<const float*>(xs); a.C = y;
+    return launch_gemm16s(a, EPI_BIAS, 0, s);
 }
 
 size_t wt_vq_workspace_bytes(int64_t N, int32_t bins) {

@@ -11,6 +11,24 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+typedef _Float16 f16x4s __attribute__((ext_vector_type(4)));
+// S32 layout of gemm16s.hip: every 32 fp32 elements of a row become 128 bytes [32 x f16 hi | 32 x f16 lo],
+// x = hi + lo * 2^-11; element e of a row -> half index (e >> 5) * 64 + (e & 31), lo 32 halves later
+__device__ __forceinline__ void store_s32_1(float* row_base, int e, float v) {
+    _Float16* p = reinterpret_cast<_Float16*>(row_base) + ((e >> 5) * 64 + (e & 31));
+    const _Float16 h = (_Float16)v;
+    p[0] = h;
+    p[32] = (_Float16)((v - (float)h) * 2048.f);
+}
+__device__ __forceinline__ void store_s32_4(float* row_base, int e, const f32x4 v) {   // e % 4 == 0
+    f16x4s hi, lo;
+    hi.x = (_Float16)v.x; hi.y = (_Float16)v.y; hi.z = (_Float16)v.z; hi.w = (_Float16)v.w;
+    lo.x = (_Float16)((v.x - (float)hi.x) * 2048.f); lo.y = (_Float16)((v.y - (float)hi.y) * 2048.f);
+    lo.z = (_Float16)((v.z - (float)hi.z) * 2048.f); lo.w = (_Float16)((v.w - (float)hi.w) * 2048.f);
+    _Float16* p = reinterpret_cast<_Float16*>(row_base) + ((e >> 5) * 64 + (e & 31));
+    *reinterpret_cast<f16x4s*>(p) = hi;
+    *reinterpret_cast<f16x4s*>(p + 32) = lo;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
@@ -119,7 +137,7 @@ int launch_conv_last(const float* x, const float* w, const float* bias, float* y
 // ------------------------------------------------------------------------------------ transpose
 // [B][R][C] -> [B][C][R] through a padded 32x32 LDS tile (coalesced on both sides).
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R,
-                                                        int C) {
+                                                        int C, int s32) {
     __shared__ float tile[32][33];
     const long boff = (long)blockIdx.z * R * C;
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
@@ -131,13 +149,17 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
         const int c = c0 + i, r = r0 + tx;
-        if (r < R && c < C) out[boff + (long)c * R + r] = tile[tx][i];
+        if (r < R && c < C) {
+            if (s32) store_s32_1(out + boff + (long)c * R, r, tile[tx][i]);
+            else out[boff + (long)c * R + r] = tile[tx][i];
+        }
     }
 }
 
-int launch_transpose(const float* in, float* out, int B, int R, int C, hipStream_t s) {
+int launch_transpose(const float* in, float* out, int B, int R, int C, hipStream_t s, int out_s32) {
+    if (out_s32 && (R % 32)) { set_error("transpose: an S32 output needs rows in multiples of 32 elements"); return -1; }
     dim3 grid((C + 31) / 32, (R + 31) / 32, B);
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, in, out, R, C);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, in, out, R, C, out_s32);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -152,7 +174,7 @@ template <int APPLY>   // 0: scale/shift only; 1: y = x*scale + shift; 2: y = sw
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float* __restrict__ scale,
                                                        float* __restrict__ shift, float* __restrict__ y, int L, int C,
-                                                       int cg, float eps) {
+                                                       int cg, float eps, int s32) {
     __shared__ float red[4];
     __shared__ float s_mean, s_rstd;
     const int g = blockIdx.x, b = blockIdx.y;
@@ -196,7 +218,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
             const float sc = rstd * gamma[g * cg + j];
             float v = xb[(long)t * C + j] * sc + (beta[g * cg + j] - mean * sc);
             if (APPLY == 2) v = v / (1.f + expf(-v));
-            yb[(long)t * C + j] = v;
+            if (s32) store_s32_1(y + ((long)b * L + t) * C, g * cg + j, v);
+            else yb[(long)t * C + j] = v;
         }
     }
 }
@@ -204,19 +227,20 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
 int launch_gn_stats(const float* x, const float* gamma, const float* beta, float* scale, float* shift, int B, int L,
                     int C, int groups, float eps, hipStream_t s) {
     hipLaunchKernelGGL(gn_stats_kernel<0>, dim3(groups, B), dim3(256), 0, s, x, gamma, beta, scale, shift,
-                       (float*)nullptr, L, C, C / groups, eps);
+                       (float*)nullptr, L, C, C / groups, eps, 0);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 int launch_gn_apply(const float* x, const float* gamma, const float* beta, float* scale, float* shift, float* y,
-                    int swish, int B, int L, int C, int groups, float eps, hipStream_t s) {
+                    int swish, int B, int L, int C, int groups, float eps, hipStream_t s, int out_s32) {
+    if (out_s32 && (C % 32)) { set_error("gn_apply: an S32 output needs C % 32 == 0"); return -1; }
     if (swish)
         hipLaunchKernelGGL(gn_stats_kernel<2>, dim3(groups, B), dim3(256), 0, s, x, gamma, beta, scale, shift, y, L, C,
-                           C / groups, eps);
+                           C / groups, eps, out_s32);
     else
         hipLaunchKernelGGL(gn_stats_kernel<1>, dim3(groups, B), dim3(256), 0, s, x, gamma, beta, scale, shift, y, L, C,
-                           C / groups, eps);
+                           C / groups, eps, out_s32);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -233,7 +257,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
                                                       const float* __restrict__ in_scale,
                                                       const float* __restrict__ in_shift,
                                                       const float* __restrict__ out_scale,
-                                                      const float* __restrict__ out_shift, float eps) {
+                                                      const float* __restrict__ out_shift, float eps, int s32) {
     constexpr int C = NV * 256;
     const int lane = threadIdx.x & 63;
     const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -282,34 +306,36 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
         const int c = (i * 64 + lane) * 4;
         const f32x4 os = *reinterpret_cast<const f32x4*>(out_scale + c);
         const f32x4 oh = *reinterpret_cast<const f32x4*>(out_shift + c);
-        *reinterpret_cast<f32x4*>(y + m * C + c) = ((v[i] - mean) * rstd) * os + oh;
+        const f32x4 o = ((v[i] - mean) * rstd) * os + oh;
+        if (s32) store_s32_4(y + m * C, c, o);       // the consumer is the S32 split-f16 GEMM
+        else *reinterpret_cast<f32x4*>(y + m * C + c) = o;
     }
 }
 
 template <int NV>
 static int launch_rownorm_nv(int mode, const float* x, float* y, long M, int L, const float* dw_w, const float* dw_b,
                              const float* is, const float* ih, const float* os, const float* oh, float eps,
-                             hipStream_t s) {
+                             hipStream_t s, int s32) {
     dim3 grid((unsigned)((M + 3) / 4));
     if (mode == RN_DWCONV)
-        hipLaunchKernelGGL((rownorm_kernel<NV, RN_DWCONV>), grid, dim3(256), 0, s, x, y, M, L, dw_w, dw_b, is, ih, os, oh, eps);
+        hipLaunchKernelGGL((rownorm_kernel<NV, RN_DWCONV>), grid, dim3(256), 0, s, x, y, M, L, dw_w, dw_b, is, ih, os, oh, eps, s32);
     else if (mode == RN_PLAIN)
-        hipLaunchKernelGGL((rownorm_kernel<NV, RN_PLAIN>), grid, dim3(256), 0, s, x, y, M, L, dw_w, dw_b, is, ih, os, oh, eps);
+        hipLaunchKernelGGL((rownorm_kernel<NV, RN_PLAIN>), grid, dim3(256), 0, s, x, y, M, L, dw_w, dw_b, is, ih, os, oh, eps, s32);
     else
-        hipLaunchKernelGGL((rownorm_kernel<NV, RN_AFFINE_IN>), grid, dim3(256), 0, s, x, y, M, L, dw_w, dw_b, is, ih, os, oh, eps);
+        hipLaunchKernelGGL((rownorm_kernel<NV, RN_AFFINE_IN>), grid, dim3(256), 0, s, x, y, M, L, dw_w, dw_b, is, ih, os, oh, eps, s32);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 int launch_rownorm(int mode, const float* x, float* y, int B, int L, int C, const float* dw_w, const float* dw_b,
                    const float* in_scale, const float* in_shift, const float* out_scale, const float* out_shift,
-                   float eps, hipStream_t s) {
+                   float eps, hipStream_t s, int out_s32) {
     const long M = (long)B * L;
     switch (C) {
-        case 256: return launch_rownorm_nv<1>(mode, x, y, M, L, dw_w, dw_b, in_scale, in_shift, out_scale, out_shift, eps, s);
-        case 512: return launch_rownorm_nv<2>(mode, x, y, M, L, dw_w, dw_b, in_scale, in_shift, out_scale, out_shift, eps, s);
-        case 768: return launch_rownorm_nv<3>(mode, x, y, M, L, dw_w, dw_b, in_scale, in_shift, out_scale, out_shift, eps, s);
-        case 1024: return launch_rownorm_nv<4>(mode, x, y, M, L, dw_w, dw_b, in_scale, in_shift, out_scale, out_shift, eps, s);
+        case 256: return launch_rownorm_nv<1>(mode, x, y, M, L, dw_w, dw_b, in_scale, in_shift, out_scale, out_shift, eps, s, out_s32);
+        case 512: return launch_rownorm_nv<2>(mode, x, y, M, L, dw_w, dw_b, in_scale, in_shift, out_scale, out_shift, eps, s, out_s32);
+        case 768: return launch_rownorm_nv<3>(mode, x, y, M, L, dw_w, dw_b, in_scale, in_shift, out_scale, out_shift, eps, s, out_s32);
+        case 1024: return launch_rownorm_nv<4>(mode, x, y, M, L, dw_w, dw_b, in_scale, in_shift, out_scale, out_shift, eps, s, out_s32);
         default: set_error("rownorm: backbone dim must be 256, 512, 768 or 1024"); return -1;
     }
 }
