@@ -111,11 +111,11 @@ int launch_codes_to_features(const int64_t* codes, const float* embed, int K, in
                              float* feat_ncl, hipStream_t s);
 struct LstmArgs {
     const float* xg0;     // [L][B][4H] (time-major) layer-0 input projection (+ both biases), packed gate order
-    const float* W0;      // [4H][H]   packed W_hh_l0
-    const float* W1;      // [4H][2H]  packed [W_ih_l1 | W_hh_l1]
+    const float* W0;      // W_hh_l0, per 16 packed gate rows: [H/16][64 lanes][4] (ops.hip lstm_step_kernel)
+    const float* W1;      // [W_ih_l1 | W_hh_l1], same packing over K = 2H
     const float* b1;      // [4H]      packed b_ih_l1 + b_hh_l1
-    float* h0;            // [2][B][H]
-    float* h1;            // [2][B][H]
+    float* h0;            // [2][H][Bp]  K-major, clip pitch Bp = B rounded up to 64 (zero-filled before step 0)
+    float* h1;            // [2][H][Bp]
     float* c0;            // [B][H]
     float* c1;            // [B][H]
     const float* x;       // [B][L][H] skip input

@@ -187,14 +187,23 @@ static int load_lstm(wt_model* M, TensorMap& tm, const std::string& prefix, int 
     const float* bhh1 = tm.get(prefix + ".lstm.bias_hh_l1", 4LL * H);
     if (!wih0 || !whh0 || !bih0 || !bhh0 || !wih1 || !whh1 || !bih1 || !bhh1) return WT_ERR_MISSING_TENSOR;
     std::vector<float> Wih0((size_t)4 * H * H), W0((size_t)4 * H * H), W1((size_t)4 * H * 2 * H), b0(4 * H), b1(4 * H);
+    // recurrent weights: per 16 packed gate rows (one workgroup), [K/16][64 lanes][4] with lane = lk*16 + li:
+    // element e of group S is W[row li][k = 16 S + 4 e + lk]  (the B operand of four k-steps in one 16-byte load)
+    auto put = [&](std::vector<float>& dst, size_t prow, int Ktot, int k, float v) {
+        const size_t blk = prow / 16, li = prow % 16;
+        const int S = k / 16, e = (k % 16) / 4, lk = k % 4;
+        dst[blk * 16 * Ktot + (size_t)S * 256 + (size_t)(lk * 16 + li) * 4 + e] = v;
+    };
     for (int g = 0; g < 4; ++g)
         for (int j = 0; j < H; ++j) {
             const size_t src = (size_t)g * H + j;
             const size_t dst = (size_t)(j / 4) * 16 + g * 4 + (j % 4);
             std::memcpy(&Wih0[dst * H], &wih0[src * H], H * sizeof(float));
-            std::memcpy(&W0[dst * H], &whh0[src * H], H * sizeof(float));
-            std::memcpy(&W1[dst * 2 * H], &wih1[src * H], H * sizeof(float));
-            std::memcpy(&W1[dst * 2 * H + H], &whh1[src * H], H * sizeof(float));
+            for (int k = 0; k < H; ++k) {
+                put(W0, dst, H, k, whh0[src * H + k]);
+                put(W1, dst, 2 * H, k, wih1[src * H + k]);
+                put(W1, dst, 2 * H, H + k, whh1[src * H + k]);
+            }
             b0[dst] = bih0[src] + bhh0[src];
             b1[dst] = bih1[src] + bhh1[src];
         }
@@ -728,7 +737,9 @@ static int plan_resblock(wt_plan* P, const ConvW& c3, const ConvW& c1, const Con
 static int plan_lstm(wt_plan* P, const LstmW& w, int B, int L, int H, int xin, const std::string& name,
                      bool elu_out = false) {
     const int xg = P->buf(name + ".xg", (size_t)B * L * 4 * H);
-    const int st = P->buf(name + ".state", (size_t)6 * B * H);   // h0[2], h1[2], c0, c1
+    const int Bp = (B + 63) / 64 * 64;                            // clip pitch of the K-major hidden state
+    const size_t st_numel = (size_t)4 * H * Bp + (size_t)2 * B * H;
+    const int st = P->buf(name + ".state", st_numel);            // h0[2][H][Bp], h1[2][H][Bp], c0[B][H], c1[B][H]
     const int y = P->buf(name, (size_t)B * L * H);
     // input projection written time-major ([L][B][4H]) so each recurrent step reads one contiguous
     // slab: the gather treats a time step as the "clip" (stride H) and the clip as the row (stride L*H)
@@ -740,10 +751,10 @@ static int plan_lstm(wt_plan* P, const LstmW& w, int B, int L, int H, int xin, c
     });
     P->step({xin, xg, st, y}, [=](const RunCtx& c) {
         float* s = P->ptr(c, st);
-        WT_HIP_CHECK(hipMemsetAsync(s, 0, (size_t)6 * B * H * sizeof(float), c.stream));
+        WT_HIP_CHECK(hipMemsetAsync(s, 0, st_numel * sizeof(float), c.stream));
         LstmArgs la;
         la.xg0 = P->ptr(c, xg); la.W0 = w.W0; la.W1 = w.W1; la.b1 = w.b1;
-        la.h0 = s; la.h1 = s + (size_t)2 * B * H; la.c0 = s + (size_t)4 * B * H; la.c1 = s + (size_t)5 * B * H;
+        la.h0 = s; la.h1 = s + (size_t)2 * H * Bp; la.c0 = s + (size_t)4 * H * Bp; la.c1 = la.c0 + (size_t)B * H;
         la.x = P->ptr(c, xin); la.y = P->ptr(c, y); la.B = B; la.L = L; la.H = H; la.elu_out = elu_out ? 1 : 0;
         for (int t = 0; t <= L; ++t)
             if (int rc = launch_lstm_step(la, t, c.stream)) return rc;

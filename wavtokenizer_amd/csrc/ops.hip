@@ -1,6 +1,7 @@
 // The non-GEMM kernels of the WavTokenizer path (gfx950): all HBM/L2-bound, 64-lane waves,
 // 16-byte accesses along the contiguous channel axis of the time-major layout.
 #include "common.h"
+#include <stdlib.h>
 
 namespace wt {
 
@@ -513,19 +514,35 @@ int launch_codes_to_features(const int64_t* codes, const float* embed, int K, in
 // SLSTM (encoder/modules/lstm.py:12-39): nn.LSTM(512, 512, num_layers=2), zero initial state, gate
 // order i,f,g,o, plus the skip add.  The recurrence is serial in time, so one launch = one
 // time step of BOTH layers, layer 1 running one step behind layer 0 (launch s: layer 0 step s,
-// layer 1 step s-1).  A workgroup owns 4 hidden units (their 16 gate rows, packed contiguously
-// at load time) for a tile of 64 clips; its 16 waves split K, v_mfma_f32_16x16x4_f32 does the
-// recurrent product, LDS adds the sixteen K slices, and each thread then updates one (clip, unit)
-// cell.  Weights stream from L2/Infinity Cache (4-8 MB per layer), h ping-pongs in HBM.
+// layer 1 step s-1).  A workgroup owns 4 hidden units (their 16 gate rows, packed at load time) for a
+// tile of 64 clips; its 16 waves split K, v_mfma_f32_16x16x4_f32 does the recurrent product, LDS adds
+// the sixteen K slices, and each thread then updates one (clip, unit) cell.
+//
+// The step is bound by the address/tag work of re-reading h (every one of the 256 workgroups reads the
+// whole hidden state: 48 MB of L2 hits per step), so the state is kept K-MAJOR, h[k][clip] with the clip
+// pitch padded to 64: a lane's 16-byte load is 4 consecutive clips of one k, a wave's load instruction is
+// 4 full 256-byte rows (8 cache lines, all bytes used; clip-major rows gave 16 half-used lines), and the
+// four elements feed four MFMAs whose row r stands for clip 4r + e.  The weights are packed per
+// workgroup as [k/16][lane][4] so that a lane's 16-byte load is its B operand for four k-steps.
 typedef float f32x4acc __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// sigmoid and tanh on the hardware exp (absolute error ~1e-7, the size of fp32 rounding of their O(1) results)
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+    const float ax = fabsf(x);
+    const float e = __expf(-2.f * ax);                       // in (0, 1]: no overflow
+    const float t = ax < 0.04f ? ax * (1.f - ax * ax * (1.f / 3.f)) : (1.f - e) * __builtin_amdgcn_rcpf(1.f + e);
+    return copysignf(t, x);
+}
 
 static constexpr int LSTM_WAVES = 16;
 
-__global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(const LstmArgs a, int s) {
+__global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(const LstmArgs a, int s_in) {
     __shared__ float red[LSTM_WAVES][64][17];
+    const int s = s_in & 0xffff, dbg = s_in >> 16;     // dbg: timing experiments only (WT_LSTM_DBG)
+    if (dbg & 1) return;
     const int H = a.H, B = a.B, L = a.L;
+    const int Bp = (B + 63) & ~63;                  // clip pitch of the K-major state
     const int nj = H / 4;
     const int layer = blockIdx.x >= nj ? 1 : 0;
     const int bj = blockIdx.x - layer * nj;
@@ -537,23 +554,17 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(const LstmAr
 
     const int Ktot = layer ? 2 * H : H;
     const int kw = Ktot / LSTM_WAVES;               // K slice of this wave: 32 (layer 0) or 64 (layer 1)
-    const int nq = kw / 16;                         // 16-wide q-steps in the slice: 2 or 4
     const int kbeg = wave * kw;
-    const float* W = (layer ? a.W1 : a.W0) + (long)(bj * 16 + li) * Ktot + kbeg + 4 * lk;
-    // source of the K slice: layer 0: h0[t-1]; layer 1: [h0[t] | h1[t-1]]
+    // packed weights of this workgroup: [Ktot/16][64 lanes][4]: element e of lane (li, lk) in group S is
+    // W[gate row bj*16 + li][k = 16 S + 4 e + lk]
+    const float* W = (layer ? a.W1 : a.W0) + (long)bj * 16 * Ktot + (long)(kbeg / 16) * 256 + lane * 4;
+    // source of the K slice: layer 0: h0[t-1]; layer 1: [h0[t] | h1[t-1]]   (each [H][Bp], K-major)
     const float* hsrc;
-    int koff;                                       // column offset inside hsrc rows
-    if (!layer) { hsrc = a.h0 + (long)((t + 1) & 1) * B * H; koff = kbeg; }
-    else if (kbeg < H) { hsrc = a.h0 + (long)(t & 1) * B * H; koff = kbeg; }
-    else { hsrc = a.h1 + (long)((t + 1) & 1) * B * H; koff = kbeg - H; }
-    const float* hrow[4];
-    bool hok[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int bb = b0 + i * 16 + li;
-        hok[i] = bb < B;
-        hrow[i] = hsrc + (long)(hok[i] ? bb : 0) * H + koff + 4 * lk;
-    }
+    int koff;                                       // first k of the slice inside hsrc
+    if (!layer) { hsrc = a.h0 + (long)((t + 1) & 1) * H * Bp; koff = kbeg; }
+    else if (kbeg < H) { hsrc = a.h0 + (long)(t & 1) * H * Bp; koff = kbeg; }
+    else { hsrc = a.h1 + (long)((t + 1) & 1) * H * Bp; koff = kbeg - H; }
+    const float* hp = hsrc + (long)(koff + lk) * Bp + b0 + 4 * li;      // k-step q: + 4 q Bp
 
     // cell-update operands (threads 0..255: one (clip, unit) each) are fetched now, under the MFMA loop
     const int br = (threadIdx.x >> 2) & 63, jj = threadIdx.x & 3;
@@ -574,37 +585,41 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(const LstmAr
     // (4 per SIMD) keep the matrix pipe fed while other waves' loads are in flight
     f32x4acc acc[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = (f32x4acc){0.f, 0.f, 0.f, 0.f};
-    f32x4 wv[4], hv[4][4];
+    for (int e = 0; e < 4; ++e) acc[e] = (f32x4acc){0.f, 0.f, 0.f, 0.f};
+    f32x4 wv[4], hv[16];
+    const int nS = kw / 16;                         // weight groups: 2 or 4; k-steps: 4 per group
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (q < nq) {
-            wv[q] = *reinterpret_cast<const f32x4*>(W + 16 * q);
+    for (int S = 0; S < 4; ++S) {
+        if (S < nS) {
+            if (dbg & 2) {
+                wv[S] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(hrow[i] + 16 * q);
-                hv[i][q] = hok[i] ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int q = 0; q < 4; ++q) hv[4 * S + q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                continue;
             }
+            wv[S] = *reinterpret_cast<const f32x4*>(W + S * 256);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hv[4 * S + q] = *reinterpret_cast<const f32x4*>(hp + (long)(4 * (4 * S + q)) * Bp);
         }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (q < nq) {
+    for (int S = 0; S < 4; ++S) {
+        if (S < nS) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[i][q][e], wv[q][e], acc[i], 0, 0, 0);
+                for (int e = 0; e < 4; ++e)         // MFMA row r <-> clip 4 r + e; k = 16 S + 4 q + lk
+                    acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[4 * S + q][e], wv[S][q], acc[e], 0, 0, 0);
         }
     }
-    // C layout 16x16: col = lane & 15 (gate row), row = 4*(lane>>4) + reg (clip)
+    // C layout 16x16: col = lane & 15 (gate row), row = 4*(lane>>4) + reg  ->  clip 4 row + e
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][i * 16 + 4 * lk + r][li] = acc[i][r];
+        for (int r = 0; r < 4; ++r) red[wave][16 * lk + 4 * r + e][li] = acc[e][r];
     __syncthreads();
 
-    if (!cell) return;
+    if (!cell || (dbg & 4)) return;
     float g4[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -615,14 +630,14 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(const LstmAr
             v += (red[w8][br][col] + red[w8 + 1][br][col]) + (red[w8 + 2][br][col] + red[w8 + 3][br][col]);
         g4[g] = v + gin[g];
     }
-    const float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]), gg = tanhf(g4[2]), og = sigmoidf_(g4[3]);
+    const float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]), gg = tanhf_(g4[2]), og = sigmoidf_(g4[3]);
     const float c = fg * c_prev + ig * gg;
-    const float h = og * tanhf(c);
+    const float h = og * tanhf_(c);
     *cst = c;
     if (!layer) {
-        a.h0[(long)(t & 1) * B * H + (long)cb * H + j] = h;
+        a.h0[((long)(t & 1) * H + j) * Bp + cb] = h;
     } else {
-        a.h1[(long)(t & 1) * B * H + (long)cb * H + j] = h;
+        a.h1[((long)(t & 1) * H + j) * Bp + cb] = h;
         const float yv = h + x_skip;                    // lstm.py:37-38 skip
         a.y[((long)cb * L + t) * H + j] = a.elu_out ? (yv > 0.f ? yv : __expf(yv) - 1.f) : yv;
     }
@@ -630,8 +645,11 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(const LstmAr
 
 int launch_lstm_step(const LstmArgs& a, int s, hipStream_t stream) {
     if (a.H != 512) { set_error("lstm: the step kernel is built for hidden size 512 (SEANet dimension)"); return -1; }
+    if (s < 0 || s > 0xffff) { set_error("lstm: step index out of range"); return -1; }
     dim3 grid(2 * (a.H / 4), (a.B + 63) / 64);
-    hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(64 * LSTM_WAVES), 0, stream, a, s);
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("WT_LSTM_DBG"); dbg = e ? atoi(e) : 0; }
+    hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(64 * LSTM_WAVES), 0, stream, a, s | (dbg << 16));
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }
