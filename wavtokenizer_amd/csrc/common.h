@@ -139,9 +139,11 @@ struct ResblockArgs {
     int B, T, C;
     long x_bstride;       // elements between clips of x (0 = T*C); x may be a trimmed view of a longer buffer
     int elu_out;          // store elu(y) (the only consumer is ELU -> down conv)
+    int out_s32;          // resblock16 only: write y in the S32 split-f16 layout (gemm16s.hip) instead of fp32
 };
 bool resblock_fusable(int C);
-int launch_resblock(const ResblockArgs& a, hipStream_t s);
+int launch_resblock(const ResblockArgs& a, hipStream_t s);      // fp32 MFMA chain (resblock.hip)
+int launch_resblock16(const ResblockArgs& a, hipStream_t s);    // split-f16 MFMAs, fp32-equivalent (resblock16.hip)
 int launch_convtr(const float* x, const float* w /*[k][Cin][Cout]*/, const float* bias, float* y, int B, int Tin,
                   int Cin, int Cout, int k, int stride, int elu_in, hipStream_t s);
 

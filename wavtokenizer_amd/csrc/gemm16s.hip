@@ -456,6 +456,7 @@ static int launch16s_tiled(const GemmArgs& a, hipStream_t s) {
             case 7: return launch16s_one<256, 128, 4, 2, 3, EPI, OUT_S32>(a, s);
             default: break;
         }
+        if (a.N <= 64) return launch16s_one<256, 64, 8, 1, 3, EPI, OUT_S32>(a, s);      // narrow outputs (down conv 1)
         // one 8-wave workgroup per CU (256 slots): 128x192 unless its last round would be mostly idle
         const long tm = (a.M + 127) / 128;
         auto cost = [&](int bn, double eff) {
@@ -481,7 +482,7 @@ int launch_gemm16s(const GemmArgs& a_in, int epi, int out_s32, hipStream_t s) {
         set_error("gemm16s: S32 operands must be 128-byte aligned"); return -1;
     }
     {
-        const long clips_per_tile = 256 / c.T_out + 2;
+        const long clips_per_tile = 256 / c.T_out + 2;      // BM <= 256
         if ((clips_per_tile * c.a_bstride + (long)c.T_in * c.a_rstride) * 4 >= 0x40000000L ||
             (long)c.N * c.w_rstride * 4 >= 0x40000000L) {
             set_error("gemm16s: operand window exceeds the 1 GiB buffer-offset range"); return -1;

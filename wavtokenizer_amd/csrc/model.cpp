@@ -476,6 +476,8 @@ static int build_splits(wt_model* M) {
     const int D = a.dim, I = a.intermediate_dim;
     auto conv = [&](const ConvW& c) { return add_split(M, c.w, (long)c.cout * c.k * c.cin); };
     auto conv32 = [&](const ConvW& c) { return (c.cin % 32) ? 0 : add_s32(M, c.w, (long)c.cout * c.k * c.cin); };
+    for (const ResStage& st : M->stages)
+        if (resblock_fusable(st.C)) if (int rc = conv32(st.down)) return rc;     // fed by the S32 output of resblock16
     if (int rc = conv32(M->bb_embed)) return rc;
     for (int i = 0; i < 4; ++i) {
         if (int rc = conv32(M->res[i].c1)) return rc;
@@ -694,7 +696,7 @@ static GemmArgs linear_args(const float* W, const float* bias, long M, int N, in
 // SEANetResnetBlock (seanet.py:62-63): y = shortcut(x) + conv1(elu(conv3(elu(x)))); returns y's buffer
 static int plan_resblock(wt_plan* P, const ConvW& c3, const ConvW& c1, const ConvW& sc, int B, long T, int xin,
                          const std::string& name, bool elu_out = false, const wt_model* e0 = nullptr, long x_off = 0,
-                         long x_bstride = 0) {
+                         long x_bstride = 0, bool out_s32 = false) {
     const int C = sc.cout;
     if (resblock_fusable(C) && !(P->flags & WT_PLAN_FLAG_KEEP_STAGES)) {
         // one fused kernel (resblock.hip); with e0 set, xin is unused and the tile is built from the waveform
@@ -707,7 +709,9 @@ static int plan_resblock(wt_plan* P, const ConvW& c3, const ConvW& c1, const Con
             a.e0_w = e0 ? e0->e0_w : nullptr; a.e0_b = e0 ? e0->e0_b : nullptr;
             a.W3 = c3.w; a.b3 = c3.b; a.W1 = c1.w; a.b1 = c1.b; a.Ws = sc.w; a.bs = sc.b;
             a.y = P->ptr(c, y); a.B = B; a.T = (int)T; a.C = C; a.elu_out = elu_out ? 1 : 0;
-            return launch_resblock(a, c.stream);
+            if (P->flags & WT_PLAN_FLAG_FP32_GEMM) return launch_resblock(a, c.stream);
+            a.out_s32 = out_s32 ? 1 : 0;
+            return launch_resblock16(a, c.stream);
         }, 1, "resblock.fused");
         return y;
     }
@@ -784,13 +788,16 @@ static int build_encode(wt_plan* P) {
     long Tc = T;
     int idx = 1;
     for (const ResStage& st : M->stages) {
+        // fused stages hand their elu'd output to the down conv pre-split (S32): both run on split-f16 MFMAs
+        const bool s32 = plan_s32(P) && resblock_fusable(st.C) && (st.C % 32 == 0) && M->s32.count(st.down.w) != 0;
         x = plan_resblock(P, st.c3, st.c1, st.sc, B, Tc, x, "enc." + std::to_string(idx), fuse_elu,
-                          (idx == 1 && fold_e0) ? M : nullptr);
+                          (idx == 1 && fold_e0) ? M : nullptr, 0, 0, s32);
         GemmArgs ad = sconv_args(st.down, B, Tc, st.r, 1);
         const int y = P->buf("enc." + std::to_string(idx + 2), (size_t)B * ad.T_out * st.down.cout);
         const int xin = x;
         P->step({xin, y}, [=](const RunCtx& c) {
             GemmArgs a = ad; a.A = P->ptr(c, xin); a.C = P->ptr(c, y);
+            if (s32) return gemm_s32(P, a, EPI_BIAS, 0, c.stream);
             return gemm_auto(P, a, fuse_elu ? PRO_NONE : PRO_ELU, EPI_BIAS, c.stream);
         });
         x = y; Tc = ad.T_out; idx += 3;

@@ -1,0 +1,368 @@
+// Fused SEANetResnetBlock (encoder/modules/seanet.py:21-63) on the f16 matrix pipe with fp32-equivalent products.
+//
+//   y = shortcut(x) + conv1(elu(conv3(elu(x))))
+//
+// Same fusion as resblock.hip (x tile with its k=3 halo in LDS, optional first encoder conv folded into the tile
+// fill, conv1 frame-local, weights resident in LDS, persistent workgroups), but every contraction runs as
+// split-f16 (x = hi + lo * 2^-11, three v_mfma_f32_32x32x16_f16 per 16-deep step, main + correction accumulator:
+// gemm16.hip) instead of v_mfma_f32_32x32x2_f32: 27 MFMA x 32 cycles per 32 frames at C = 32 where the fp32 pipe
+// needs 72 x 64.  The split is done ONCE per element when the tile is filled (ELU too, not once per tap), the LDS
+// images hold rows of [hi | lo] f16 with XOR-swizzled 16-byte chunks so every ds_read_b128 fragment read is
+// conflict-free, and the weights are the MFMA's A operand: the accumulator comes out with the frame on the lane and
+// 4-channel runs in the registers, so the epilogue stores 16 bytes (fp32) or 8 + 8 bytes (S32, for the split-f16
+// down conv that follows) per lane.
+#include "common.h"
+
+namespace wt {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float rb16_elu(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
+
+__device__ __forceinline__ void rb16_split8(const float* v, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const _Float16 h = (_Float16)v[i];
+        hi[i] = h;
+        lo[i] = (_Float16)((v[i] - (float)h) * 2048.f);
+    }
+}
+__device__ __forceinline__ void rb16_split4(const f32x4 v, f16x4& hi, f16x4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const _Float16 h = (_Float16)v[i];
+        hi[i] = h;
+        lo[i] = (_Float16)((v[i] - (float)h) * 2048.f);
+    }
+}
+
+// LDS images (bytes).  An activation row of CH channels is CH*4 bytes: per 32 channels a 128-byte group
+// [32 x hi | 32 x lo] (CH = 16: one 64-byte group [16 hi | 16 lo]); the 16-byte chunk c of row r is stored at chunk
+// c ^ swz(r) with swz chosen per row pitch so that 16 lanes reading the same logical chunk of 16 different rows
+// cover all 64 banks:  64-byte rows: (r >> 2) & 3, 128-byte rows: (r >> 1) & 7, 256-byte rows: r & 15.
+template <int CH>
+struct RbRow {
+    static constexpr int bytes = CH * 4;
+    static constexpr int chunks = bytes / 16;
+    __device__ static __forceinline__ int swz(int r) {
+        return bytes == 64 ? ((r >> 2) & 3) : (bytes == 128 ? ((r >> 1) & 7) : (r & 15));
+    }
+    // byte offset of the 8-half chunk holding channels ci .. ci+7 (ci % 8 == 0) of row r; lo = the lo half
+    __device__ static __forceinline__ int off(int r, int ci, int lo) {
+        constexpr int G = CH < 32 ? CH : 32;                    // channels per [hi | lo] group
+        const int c = (ci / G) * (G / 4) + lo * (G / 8) + (ci % G) / 8;
+        return r * bytes + ((c ^ swz(r)) * 16);
+    }
+};
+
+template <int C, int ROWS>
+struct Rb16Layout {
+    static constexpr int H = C / 2;
+    static constexpr int N1 = H < 32 ? 32 : H;       // conv3 output rows padded to an MFMA tile
+    static constexpr int K1 = 3 * C, K2 = H + C;
+    static constexpr int NX = ROWS + 2;
+    static constexpr int off_xe = 0;                                 // elu(x), rows -1 .. ROWS
+    static constexpr int off_xr = off_xe + NX * C * 4;               // raw x, rows 0 .. ROWS-1
+    static constexpr int off_he = off_xr + ROWS * C * 4;             // elu(hidden)
+    static constexpr int off_w3 = off_he + ROWS * H * 4;             // [K1/16][hi, lo][N1 rows][32 B]
+    static constexpr int off_w2 = off_w3 + (K1 / 16) * 2 * N1 * 32;  // [K2/16][hi, lo][C rows][32 B]
+    static constexpr int off_b = off_w2 + (K2 / 16) * 2 * C * 32;    // b3[N1], b12[C] fp32
+    static constexpr int off_wav = off_b + (N1 + C) * 4;             // folded first conv: ROWS + 8 samples
+    static constexpr int total = off_wav + (ROWS + 8) * 4;
+};
+
+// weight image: 16-deep k-step ks, part hl, row n: 32 bytes = k 16 ks .. +15 as two 16-byte chunks (k half h),
+// stored at chunk h ^ ((n >> 3) & 1): conflict-free for the 16-lane groups of a ds_read_b128
+__device__ __forceinline__ int rb16_woff(int rows, int ks, int hl, int n, int h) {
+    return ((ks * 2 + hl) * rows + n) * 32 + ((h ^ ((n >> 3) & 1)) * 16);
+}
+
+template <int C, int ROWS, int FOLD>
+__global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs a) {
+    using L = Rb16Layout<C, ROWS>;
+    using XR = RbRow<C>;
+    using HR = RbRow<L::H>;
+    constexpr int NT = ROWS * 2;                     // one wave per 32 frames
+    extern __shared__ __attribute__((aligned(256))) char smem16[];
+    char* xe = smem16 + L::off_xe;
+    char* xr = smem16 + L::off_xr;
+    char* he = smem16 + L::off_he;
+    char* w3 = smem16 + L::off_w3;
+    char* w2 = smem16 + L::off_w2;
+    float* bb = reinterpret_cast<float*>(smem16 + L::off_b);
+    float* wtile = reinterpret_cast<float*>(smem16 + L::off_wav);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // ---- resident split weights.  W3 [H][3][C] -> rows n < H (n >= H: zero padding), k = tap*C + ci;
+    //      W2 = [W1 (C x H) | Ws (C x C)] -> rows n < C, k < H from conv1, then the shortcut
+    for (int e = tid; e < L::N1 * (L::K1 / 8); e += NT) {
+        const int n = e / (L::K1 / 8), k8 = (e - n * (L::K1 / 8)) * 8;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = n < L::H ? a.W3[(long)n * L::K1 + k8 + i] : 0.f;
+        f16x8 hi, lo;
+        rb16_split8(v, hi, lo);
+        *reinterpret_cast<f16x8*>(w3 + rb16_woff(L::N1, k8 / 16, 0, n, (k8 / 8) & 1)) = hi;
+        *reinterpret_cast<f16x8*>(w3 + rb16_woff(L::N1, k8 / 16, 1, n, (k8 / 8) & 1)) = lo;
+    }
+    for (int e = tid; e < C * (L::K2 / 8); e += NT) {
+        const int n = e / (L::K2 / 8), k8 = (e - n * (L::K2 / 8)) * 8;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            v[i] = k8 < L::H ? a.W1[(long)n * L::H + k8 + i] : a.Ws[(long)n * C + (k8 - L::H) + i];
+        f16x8 hi, lo;
+        rb16_split8(v, hi, lo);
+        *reinterpret_cast<f16x8*>(w2 + rb16_woff(C, k8 / 16, 0, n, (k8 / 8) & 1)) = hi;
+        *reinterpret_cast<f16x8*>(w2 + rb16_woff(C, k8 / 16, 1, n, (k8 / 8) & 1)) = lo;
+    }
+    for (int e = tid; e < L::N1 + C; e += NT)
+        bb[e] = e < L::N1 ? (e < L::H ? a.b3[e] : 0.f) : (a.b1[e - L::N1] + a.bs[e - L::N1]);
+
+    const long xbs = a.x_bstride ? a.x_bstride : (long)a.T * C;
+    const int tiles_per_clip = (a.T + ROWS - 1) / ROWS;
+    const long n_tiles = (long)a.B * tiles_per_clip;
+    const int Tp1 = a.T > 1 ? a.T : 2;               // reflect pad 1 (k=3): conv.py:86-91
+    const int Tp3 = a.T > 3 ? a.T : 4;               // reflect pad 3 (k=7)
+
+    // ---- tile fill: item = (x row r in -1 .. ROWS, 8-channel chunk); the global loads of tile i+1 are issued before
+    // the contractions of tile i and parked in registers
+    constexpr int CPR = C / 8;                                       // chunks per row
+    constexpr int ITEMS = (L::NX * CPR + NT - 1) / NT;
+    constexpr int WAVN = ROWS + 8;                                   // waveform samples per tile (k=7 halo + k=3 halo)
+    f32x4 px[FOLD ? 1 : ITEMS][2];
+    float pw = 0.f;
+    auto prefetch = [&](long tile) {
+        const int b = (int)(tile / tiles_per_clip);
+        const int t0 = (int)(tile - (long)b * tiles_per_clip) * ROWS;
+        if (FOLD) {
+            if (tid < WAVN) {                                        // sample index t0 - 4 + tid, k=7 reflect
+                int p = t0 - 4 + tid;
+                p = p < 0 ? -p : p;
+                p = p >= Tp3 ? 2 * (Tp3 - 1) - p : p;
+                pw = (p >= 0 && p < a.T) ? a.wav[(long)b * a.T + p] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int e = tid + it * NT;
+                const int r = e / CPR, c8 = (e - r * CPR) * 8;
+                int pos = t0 - 1 + r;
+                pos = pos < 0 ? -pos : pos;
+                pos = pos >= Tp1 ? 2 * (Tp1 - 1) - pos : pos;
+                f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+                if (e < L::NX * CPR && pos >= 0 && pos < a.T) {
+                    const float* src = a.x + (long)b * xbs + (long)pos * C + c8;
+                    v0 = *reinterpret_cast<const f32x4*>(src);
+                    v1 = *reinterpret_cast<const f32x4*>(src + 4);
+                }
+                px[it][0] = v0; px[it][1] = v1;
+            }
+        }
+    };
+    // one item into the LDS images: raw split into xr (rows 0 .. ROWS-1 only), elu split into xe
+    auto put_item = [&](int r, int c8, const float* v) {
+        f16x8 hi, lo;
+        if (r >= 1 && r <= ROWS) {
+            rb16_split8(v, hi, lo);
+            *reinterpret_cast<f16x8*>(xr + XR::off(r - 1, c8, 0)) = hi;
+            *reinterpret_cast<f16x8*>(xr + XR::off(r - 1, c8, 1)) = lo;
+        }
+        float ev[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ev[i] = rb16_elu(v[i]);
+        rb16_split8(ev, hi, lo);
+        *reinterpret_cast<f16x8*>(xe + XR::off(r, c8, 0)) = hi;
+        *reinterpret_cast<f16x8*>(xe + XR::off(r, c8, 1)) = lo;
+    };
+    if ((long)blockIdx.x < n_tiles) prefetch(blockIdx.x);
+
+    const int fl = lane & 31, fh = lane >> 5;        // MFMA lane: (row or column fl, k half fh)
+    const int row0 = wave * 32;                      // this wave's frames inside the tile
+    constexpr float LO_SCALE = 1.f / 2048.f;
+
+    for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int b = (int)(tile / tiles_per_clip);
+        const int t0 = (int)(tile - (long)b * tiles_per_clip) * ROWS;
+        __syncthreads();                             // previous tile fully consumed (and weights landed)
+        if (FOLD) {
+            // first encoder conv from the staged samples: x[f] = b + sum_j w[j] * wav[refl(f + j - 3)]
+            if (tid < WAVN) wtile[tid] = pw;
+            __syncthreads();
+            const bool direct = (t0 - 4 >= 0) && (t0 + ROWS + 4 <= a.T);      // window not reflected itself
+            for (int e = tid; e < L::NX * CPR; e += NT) {
+                const int r = e / CPR, c8 = (e - r * CPR) * 8;
+                int pos = t0 - 1 + r;                // frame of this x row, k=3 reflect
+                pos = pos < 0 ? -pos : pos;
+                pos = pos >= Tp1 ? 2 * (Tp1 - 1) - pos : pos;
+                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (pos >= 0 && pos < a.T) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = a.e0_b[c8 + i];
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) {
+                        // the staged window holds raw positions t0-4 .. t0+ROWS+3; a reflected frame near a clip
+                        // edge may need samples outside it, which are re-read from memory (rare)
+                        int p = pos + j - 3;
+                        p = p < 0 ? -p : p;
+                        p = p >= Tp3 ? 2 * (Tp3 - 1) - p : p;
+                        float xv = 0.f;
+                        if (p >= 0 && p < a.T) {
+                            const int wi = p - (t0 - 4);
+                            xv = (direct && wi >= 0 && wi < WAVN) ? wtile[wi] : a.wav[(long)b * a.T + p];
+                        }
+                        const f32x4 w0 = *reinterpret_cast<const f32x4*>(a.e0_w + j * C + c8);
+                        const f32x4 w1 = *reinterpret_cast<const f32x4*>(a.e0_w + j * C + c8 + 4);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { v[i] += xv * w0[i]; v[4 + i] += xv * w1[i]; }
+                    }
+                }
+                put_item(r, c8, v);
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int e = tid + it * NT;
+                if (e < L::NX * CPR) {
+                    const int r = e / CPR, c8 = (e - r * CPR) * 8;
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { v[i] = px[it][0][i]; v[4 + i] = px[it][1][i]; }
+                    put_item(r, c8, v);
+                }
+            }
+        }
+        __syncthreads();
+        if (tile + gridDim.x < n_tiles) prefetch(tile + gridDim.x);
+
+        // ---- conv3 (transposed): h[n][frame] = sum over (tap, ci) W3[n][tap][ci] * elu(x)[frame + tap - 1][ci]
+        constexpr int TN1 = L::N1 / 32;
+        f32x16 a1m[TN1], a1c[TN1];
+#pragma unroll
+        for (int j = 0; j < TN1; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { a1m[j][r] = 0.f; a1c[j][r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < L::K1 / 16; ++ks) {
+            const int tap = (ks * 16) / C, ci = (ks * 16) % C + 8 * fh;
+            const int xrow = row0 + fl + tap;                    // xe row index = frame + 1 + (tap - 1)
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(xe + XR::off(xrow, ci, 0));
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(xe + XR::off(xrow, ci, 1));
+#pragma unroll
+            for (int j = 0; j < TN1; ++j) {
+                const f16x8 wh = *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, ks, 0, j * 32 + fl, fh));
+                const f16x8 wl = *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, ks, 1, j * 32 + fl, fh));
+                a1m[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, a1m[j], 0, 0, 0);
+                a1c[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, a1c[j], 0, 0, 0);
+                a1c[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, a1c[j], 0, 0, 0);
+            }
+        }
+        // elu(h + b3), split, into this wave's own rows of he.  D layout: lane -> frame fl, register r -> row
+        // n = 32 j + (r & 3) + 8 (r >> 2) + 4 fh
+#pragma unroll
+        for (int j = 0; j < TN1; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = j * 32 + 8 * g + 4 * fh;
+                if (n < L::H) {
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        v[i] = rb16_elu(a1m[j][4 * g + i] + a1c[j][4 * g + i] * LO_SCALE + bb[n + i]);
+                    f16x4 hi, lo;
+                    rb16_split4(v, hi, lo);
+                    *reinterpret_cast<f16x4*>(he + HR::off(row0 + fl, n & ~7, 0) + (n & 7) * 2) = hi;
+                    *reinterpret_cast<f16x4*>(he + HR::off(row0 + fl, n & ~7, 1) + (n & 7) * 2) = lo;
+                }
+            }
+        // no barrier: a wave reads back only its own he rows, and a wave's LDS operations execute in order
+
+        // ---- y[n][frame] = [W1 | Ws][n] . [elu(h) | x][frame] + (b1 + bs)
+        constexpr int TN2 = C / 32;
+        f32x16 a2m[TN2], a2c[TN2];
+#pragma unroll
+        for (int j = 0; j < TN2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { a2m[j][r] = 0.f; a2c[j][r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < L::K2 / 16; ++ks) {
+            f16x8 bh, bl;
+            if (ks < L::H / 16) {
+                bh = *reinterpret_cast<const f16x8*>(he + HR::off(row0 + fl, ks * 16 + 8 * fh, 0));
+                bl = *reinterpret_cast<const f16x8*>(he + HR::off(row0 + fl, ks * 16 + 8 * fh, 1));
+            } else {
+                const int ci = ks * 16 - L::H + 8 * fh;
+                bh = *reinterpret_cast<const f16x8*>(xr + XR::off(row0 + fl, ci, 0));
+                bl = *reinterpret_cast<const f16x8*>(xr + XR::off(row0 + fl, ci, 1));
+            }
+#pragma unroll
+            for (int j = 0; j < TN2; ++j) {
+                const f16x8 wh = *reinterpret_cast<const f16x8*>(w2 + rb16_woff(C, ks, 0, j * 32 + fl, fh));
+                const f16x8 wl = *reinterpret_cast<const f16x8*>(w2 + rb16_woff(C, ks, 1, j * 32 + fl, fh));
+                a2m[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, a2m[j], 0, 0, 0);
+                a2c[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, a2c[j], 0, 0, 0);
+                a2c[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, a2c[j], 0, 0, 0);
+            }
+        }
+        const int t = t0 + row0 + fl;
+        if (t < a.T) {
+            float* yrow = a.y + ((long)b * a.T + t) * C;
+#pragma unroll
+            for (int j = 0; j < TN2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = j * 32 + 8 * g + 4 * fh;
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v[i] = a2m[j][4 * g + i] + a2c[j][4 * g + i] * LO_SCALE + bb[L::N1 + n + i];
+                        if (a.elu_out) v[i] = rb16_elu(v[i]);
+                    }
+                    if (a.out_s32) {
+                        f16x4 hi, lo;
+                        rb16_split4(v, hi, lo);
+                        _Float16* gq = reinterpret_cast<_Float16*>(yrow) + ((n >> 5) * 64 + (n & 31));
+                        *reinterpret_cast<f16x4*>(gq) = hi;
+                        *reinterpret_cast<f16x4*>(gq + 32) = lo;
+                    } else {
+                        *reinterpret_cast<f32x4*>(yrow + n) = v;
+                    }
+                }
+        }
+    }
+}
+
+template <int C, int ROWS, int FOLD>
+static int launch_rb16(const ResblockArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    constexpr size_t smem = (size_t)Rb16Layout<C, ROWS>::total;
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    auto kern = resblock16_kernel<C, ROWS, FOLD>;
+    if (!attr_set) {
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)smem));
+        attr_set = true;
+    }
+    const long tiles = (long)a.B * ((a.T + ROWS - 1) / ROWS);
+    const int per_cu = (int)(160 * 1024 / smem) < 4 ? (int)(160 * 1024 / smem) : 4;
+    const long grid = tiles < 256L * per_cu ? tiles : 256L * per_cu;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(ROWS * 2), smem, s, a);
+    WT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_resblock16(const ResblockArgs& a, hipStream_t s) {
+    if (a.wav && a.C != 32) { set_error("resblock16: the folded first conv needs C == 32"); return -1; }
+    if (!a.wav && ((reinterpret_cast<uintptr_t>(a.x) & 15) || (a.x_bstride % 4))) {
+        set_error("resblock16: x must be 16-byte aligned"); return -1;
+    }
+    if (a.C == 32) return a.wav ? launch_rb16<32, 128, 1>(a, s) : launch_rb16<32, 128, 0>(a, s);
+    if (a.C == 64) return launch_rb16<64, 128, 0>(a, s);
+    set_error("resblock16: fused kernel exists for C = 32 and 64");
+    return -1;
+}
+
+}  // namespace wt
