@@ -179,6 +179,18 @@ __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs
         *reinterpret_cast<f16x8*>(xe + XR::off(r, c8, 1)) = lo;
     };
     if ((long)blockIdx.x < n_tiles) prefetch(blockIdx.x);
+    // folded first conv: this thread always fills the same 8 channels, so its 7 x 8 taps live in registers
+    static_assert(NT % CPR == 0, "an item's channel chunk must be fixed per thread");
+    const int c8_fixed = (tid % CPR) * 8;
+    float e0w[FOLD ? 7 : 1][8], e0b[8];
+    if (FOLD) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) e0w[j][i] = a.e0_w[j * C + c8_fixed + i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e0b[i] = a.e0_b[c8_fixed + i];
+    }
 
     const int fl = lane & 31, fh = lane >> 5;        // MFMA lane: (row or column fl, k half fh)
     const int row0 = wave * 32;                      // this wave's frames inside the tile
@@ -193,34 +205,44 @@ __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs
             if (tid < WAVN) wtile[tid] = pw;
             __syncthreads();
             const bool direct = (t0 - 4 >= 0) && (t0 + ROWS + 4 <= a.T);      // window not reflected itself
+            const bool interior = direct && (t0 + ROWS < a.T);                 // no reflected x row either
             for (int e = tid; e < L::NX * CPR; e += NT) {
-                const int r = e / CPR, c8 = (e - r * CPR) * 8;
-                int pos = t0 - 1 + r;                // frame of this x row, k=3 reflect
-                pos = pos < 0 ? -pos : pos;
-                pos = pos >= Tp1 ? 2 * (Tp1 - 1) - pos : pos;
+                const int r = e / CPR;               // the 8-channel chunk of an item is fixed per thread (NT % CPR == 0)
                 float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if (pos >= 0 && pos < a.T) {
+                if (interior) {                      // x row r = frame t0-1+r needs samples wtile[r .. r+6]
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = a.e0_b[c8 + i];
+                    for (int i = 0; i < 8; ++i) v[i] = e0b[i];
 #pragma unroll
                     for (int j = 0; j < 7; ++j) {
-                        // the staged window holds raw positions t0-4 .. t0+ROWS+3; a reflected frame near a clip
-                        // edge may need samples outside it, which are re-read from memory (rare)
-                        int p = pos + j - 3;
-                        p = p < 0 ? -p : p;
-                        p = p >= Tp3 ? 2 * (Tp3 - 1) - p : p;
-                        float xv = 0.f;
-                        if (p >= 0 && p < a.T) {
-                            const int wi = p - (t0 - 4);
-                            xv = (direct && wi >= 0 && wi < WAVN) ? wtile[wi] : a.wav[(long)b * a.T + p];
-                        }
-                        const f32x4 w0 = *reinterpret_cast<const f32x4*>(a.e0_w + j * C + c8);
-                        const f32x4 w1 = *reinterpret_cast<const f32x4*>(a.e0_w + j * C + c8 + 4);
+                        const float xv = wtile[r + j];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) { v[i] += xv * w0[i]; v[4 + i] += xv * w1[i]; }
+                        for (int i = 0; i < 8; ++i) v[i] += xv * e0w[j][i];
+                    }
+                } else {
+                    int pos = t0 - 1 + r;            // frame of this x row, k=3 reflect
+                    pos = pos < 0 ? -pos : pos;
+                    pos = pos >= Tp1 ? 2 * (Tp1 - 1) - pos : pos;
+                    if (pos >= 0 && pos < a.T) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] = e0b[i];
+#pragma unroll
+                        for (int j = 0; j < 7; ++j) {
+                            // the staged window holds raw positions t0-4 .. t0+ROWS+3; a reflected frame near a clip
+                            // edge may need samples outside it, which are re-read from memory (rare)
+                            int p = pos + j - 3;
+                            p = p < 0 ? -p : p;
+                            p = p >= Tp3 ? 2 * (Tp3 - 1) - p : p;
+                            float xv = 0.f;
+                            if (p >= 0 && p < a.T) {
+                                const int wi = p - (t0 - 4);
+                                xv = (direct && wi >= 0 && wi < WAVN) ? wtile[wi] : a.wav[(long)b * a.T + p];
+                            }
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) v[i] += xv * e0w[j][i];
+                        }
                     }
                 }
-                put_item(r, c8, v);
+                put_item(r, c8_fixed, v);
             }
         } else {
 #pragma unroll
@@ -307,9 +329,11 @@ __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs
                 a2c[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, a2c[j], 0, 0, 0);
             }
         }
-        const int t = t0 + row0 + fl;
-        if (t < a.T) {
-            float* yrow = a.y + ((long)b * a.T + t) * C;
+        // The wave's 32 output frames are one contiguous block of y.  Each lane holds 4-channel runs of ONE frame, so
+        // the tile is staged in the wave's own xr rows (free now: the shortcut was their last reader, and they are
+        // private to the wave) and written out with every lane storing 16 bytes of a full 128-byte line.
+        {
+            char* st = xr + row0 * XR::bytes;                       // 32 rows x C*4 bytes, chunk-swizzled like xr
 #pragma unroll
             for (int j = 0; j < TN2; ++j)
 #pragma unroll
@@ -321,16 +345,25 @@ __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs
                         v[i] = a2m[j][4 * g + i] + a2c[j][4 * g + i] * LO_SCALE + bb[L::N1 + n + i];
                         if (a.elu_out) v[i] = rb16_elu(v[i]);
                     }
-                    if (a.out_s32) {
+                    if (a.out_s32) {                                // S32: chunk (n/32)*8 + n%32/8 holds hi, + 4 holds lo
                         f16x4 hi, lo;
                         rb16_split4(v, hi, lo);
-                        _Float16* gq = reinterpret_cast<_Float16*>(yrow) + ((n >> 5) * 64 + (n & 31));
-                        *reinterpret_cast<f16x4*>(gq) = hi;
-                        *reinterpret_cast<f16x4*>(gq + 32) = lo;
-                    } else {
-                        *reinterpret_cast<f32x4*>(yrow + n) = v;
+                        const int ch = (n >> 5) * 8 + ((n & 31) >> 3);
+                        *reinterpret_cast<f16x4*>(st + fl * XR::bytes + ((ch ^ XR::swz(fl)) * 16) + (n & 7) * 2) = hi;
+                        *reinterpret_cast<f16x4*>(st + fl * XR::bytes + (((ch + 4) ^ XR::swz(fl)) * 16) + (n & 7) * 2) = lo;
+                    } else {                                        // fp32: chunk n/4
+                        *reinterpret_cast<f32x4*>(st + fl * XR::bytes + (((n >> 2) ^ XR::swz(fl)) * 16)) = v;
                     }
                 }
+            constexpr int LPR = XR::chunks;                         // lanes per row: 8 (C = 32) or 16 (C = 64)
+            constexpr int RPI = 64 / LPR;                           // rows per store instruction
+            const long tbase = (long)b * a.T + t0 + row0;
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; ++it) {
+                const int r = it * RPI + lane / LPR, ch = lane % LPR;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(st + r * XR::bytes + ((ch ^ XR::swz(r)) * 16));
+                if (t0 + row0 + r < a.T) *reinterpret_cast<f32x4*>(a.y + (tbase + r) * C + ch * 4) = v;
+            }
         }
     }
 }
