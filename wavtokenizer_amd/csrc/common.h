@@ -36,7 +36,15 @@ enum Epi : int {
     EPI_ARGMAX = 6,          // VQ: per-row argmax of -(xx - 2 acc + ee[n]) over this wave's columns
     EPI_SCALE = 7,           // C = alpha * acc
     EPI_BIAS_ROW = 8,        // C = acc + bias[m]
-    EPI_BIAS_RES_ELU = 9     // C = elu((acc + bias[n]) + R[m][n])   (the only consumer applies ELU)
+    EPI_BIAS_RES_ELU = 9,    // C = elu((acc + bias[n]) + R[m][n])   (the only consumer applies ELU)
+    EPI_BIAS_ELU = 10        // C = elu(acc + bias[n])               (gemm16s only)
+};
+// gemm16s output formats: what is written to C (and C2)
+enum Out16s : int {
+    OUT_F32 = 0,             // C fp32
+    OUT_S32 = 1,             // C in the S32 split-f16 layout
+    OUT_S32_DUAL_ELU = 2,    // C = S32(v) and C2 = S32(elu(v)): a tensor read both raw (shortcut) and through ELU (conv)
+    OUT_F32_AND_S32 = 3      // C = fp32 v and C2 = S32(v): a tensor read by fp32 kernels and by a split-f16 GEMM
 };
 enum PadMode : int { PAD_ZERO = 0, PAD_REFLECT = 1 };
 
@@ -58,6 +66,7 @@ struct GemmArgs {
     // C
     float* C = nullptr;
     long c_rstride = 0;
+    float* C2 = nullptr;  // gemm16s second output (Out16s), row stride c_rstride
     const float* R = nullptr;
     long r_rstride = 0;
     const float* gamma = nullptr;
@@ -84,7 +93,8 @@ int gemm16_vq_parts(int N);
 int launch_split_f16x2(const float* w, void* hi, void* lo, long n, hipStream_t s);   // weights -> f16 (hi, lo) arrays (gemm16.hip)
 // gemm16s.hip: both operands pre-split in the S32 layout (128-byte groups [32 x f16 hi | 32 x f16 lo], same
 // footprint and strides as the fp32 array); a.A / a.W_hi point at S32 data, out_s32 selects an S32 C
-int launch_gemm16s(const GemmArgs& a, int epi, int out_s32, hipStream_t s);
+int launch_gemm16s(const GemmArgs& a, int epi, int out, hipStream_t s);     // out: Out16s
+int gemm16s_vq_parts(int N);
 int launch_split_s32(const float* x, void* out, long n, hipStream_t s);
 
 // ------------------------------------------------------------------------ non-GEMM kernels
@@ -122,6 +132,7 @@ struct LstmArgs {
     float* y;             // [B][L][H] output = h1 + x
     int B, L, H;
     int elu_out;          // store elu(h1 + x): the only consumer is ELU -> conv (seanet.py:136-139)
+    int out_s32;          // write y in the S32 split-f16 layout (its consumer is a gemm16s conv)
 };
 int launch_lstm_step(const LstmArgs& a, int s, hipStream_t stream);
 struct ResblockArgs {

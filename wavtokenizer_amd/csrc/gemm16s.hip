@@ -81,7 +81,7 @@ __device__ __forceinline__ void wait_vm_lgkm() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int EPI, int OUT_S32>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int EPI, int OUT>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(const GemmArgs p) {
     constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -318,7 +318,39 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
         return v;
     };
 
-    if constexpr (EPI == EPI_HEAD) {
+    if constexpr (EPI == EPI_ARGMAX) {
+        // VQ (core_vq.py:176-182): per row, the best of this wave's WN columns of -(|x|^2 - 2 x.e + |e|^2), lowest
+        // index on ties; a lane holds one row (and its partner lane + 32 the other half of the columns)
+        const int part = bn * WAVES_N + wn;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m_w + i * 32 + row_l;
+            const float xx = (m < p.M) ? p.vq_xx[m] : 0.f;
+            float best = -INFINITY;
+            int bidx = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n_w + j * 32 + 8 * g + col_h;
+                    if (n >= p.N) continue;
+                    const f32x4 dot = acc4(i, j, g);
+                    const f32x4 ee = *reinterpret_cast<const f32x4*>(p.vq_ee + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float d = -((xx - 2.f * dot[e]) + ee[e]);
+                        if (d > best) { best = d; bidx = n + e; }        // ascending n within the lane: strict > keeps the lowest
+                    }
+                }
+            const float ov = __shfl_xor(best, 32, 64);
+            const int oi = __shfl_xor(bidx, 32, 64);
+            if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+            if (lane < 32 && m < p.M) {
+                p.vq_pval[(long)m * p.vq_nparts + part] = best;
+                p.vq_pidx[(long)m * p.vq_nparts + part] = bidx;
+            }
+        }
+    } else if constexpr (EPI == EPI_HEAD) {
         static_assert(TN % 2 == 0, "head epilogue pairs column tiles");
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -342,7 +374,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
                         im[e] = mag * sinf(ph[e]);
                     }
                     const int f = (pc >> 6) * 32 + (pc & 31);          // bin slot
-                    if (OUT_S32) {
+                    if (OUT == OUT_S32) {
                         store_s32_x4(crow, f, re);
                         store_s32_x4(crow, p.head_kb + f, im);
                     } else {
@@ -370,14 +402,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
                     } else if (EPI == EPI_BIAS_RES_ELU) {
                         v = v + *reinterpret_cast<const f32x4*>(p.R + (long)m * p.r_rstride + n);
                         v.x = elu_s(v.x); v.y = elu_s(v.y); v.z = elu_s(v.z); v.w = elu_s(v.w);
+                    } else if (EPI == EPI_BIAS_ELU) {
+                        v.x = elu_s(v.x); v.y = elu_s(v.y); v.z = elu_s(v.z); v.w = elu_s(v.w);
                     } else if (EPI == EPI_BIAS_GELU) {
                         v.x = gelu_erf_s(v.x); v.y = gelu_erf_s(v.y); v.z = gelu_erf_s(v.z); v.w = gelu_erf_s(v.w);
                     } else if (EPI == EPI_BIAS_GAMMA_RES) {
                         const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + n);
                         v = *reinterpret_cast<const f32x4*>(p.R + (long)m * p.r_rstride + n) + gm * v;
                     }
-                    if (OUT_S32) store_s32_x4(crow, n, v);
+                    if (OUT == OUT_S32 || OUT == OUT_S32_DUAL_ELU) store_s32_x4(crow, n, v);
                     else *reinterpret_cast<f32x4*>(crow + n) = v;
+                    if (OUT == OUT_S32_DUAL_ELU) {
+                        f32x4 ev;
+                        ev.x = elu_s(v.x); ev.y = elu_s(v.y); ev.z = elu_s(v.z); ev.w = elu_s(v.w);
+                        store_s32_x4(p.C2 + (long)z * p.zC + (long)m * p.c_rstride, n, ev);
+                    } else if (OUT == OUT_F32_AND_S32) {
+                        store_s32_x4(p.C2 + (long)z * p.zC + (long)m * p.c_rstride, n, v);
+                    }
                 }
         }
     }
@@ -405,7 +446,7 @@ int launch_split_s32(const float* x, void* out, long n, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------- host side
-template <int BM, int BN, int WMs, int WNs, int NSTAGE, int EPI, int OUT_S32>
+template <int BM, int BN, int WMs, int WNs, int NSTAGE, int EPI, int OUT>
 static int launch16s_one(const GemmArgs& a, hipStream_t s) {
     static bool attr_set = false;
     constexpr size_t stage_bytes = (size_t)NSTAGE * (BM + BN) * 128;
@@ -415,7 +456,7 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
     constexpr size_t smem_max = smem_want < smem_cap ? smem_want : smem_cap;
     static_assert(stage_bytes + 2 * BM * sizeof(unsigned) <= smem_cap, "LDS budget");
     if (smem > smem_cap) { set_error("gemm16s: too many taps for this tile's LDS budget"); return -1; }
-    auto kern = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT_S32>;
+    auto kern = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT>;
     if (!attr_set) {
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)smem_max));
@@ -442,35 +483,40 @@ static int tile16s_override() {
     return e ? atoi(e) : -1;
 }
 
-template <int EPI, int OUT_S32>
+template <int EPI, int OUT>
 static int launch16s_tiled(const GemmArgs& a, hipStream_t s) {
     if constexpr (EPI == EPI_HEAD) {
-        return launch16s_one<128, 128, 4, 2, 3, EPI, OUT_S32>(a, s);      // wave tile 32x64: paired column tiles
+        return launch16s_one<128, 128, 4, 2, 3, EPI, OUT>(a, s);      // wave tile 32x64: paired column tiles
+    } else if constexpr (EPI == EPI_ARGMAX) {
+        return launch16s_one<128, 192, 4, 2, 3, EPI, OUT>(a, s);      // gemm16s_vq_parts() assumes this tile
     } else {
         switch (tile16s_override()) {       // experiment hook (tools/linear_bench.py)
-            case 1: return launch16s_one<128, 96, 4, 1, 2, EPI, OUT_S32>(a, s);
-            case 2: return launch16s_one<128, 192, 4, 2, 3, EPI, OUT_S32>(a, s);
-            case 3: return launch16s_one<128, 128, 4, 2, 3, EPI, OUT_S32>(a, s);
-            case 5: return launch16s_one<128, 128, 4, 2, 4, EPI, OUT_S32>(a, s);
-            case 6: return launch16s_one<128, 192, 4, 2, 2, EPI, OUT_S32>(a, s);
-            case 7: return launch16s_one<256, 128, 4, 2, 3, EPI, OUT_S32>(a, s);
+            case 1: return launch16s_one<128, 96, 4, 1, 2, EPI, OUT>(a, s);
+            case 2: return launch16s_one<128, 192, 4, 2, 3, EPI, OUT>(a, s);
+            case 3: return launch16s_one<128, 128, 4, 2, 3, EPI, OUT>(a, s);
+            case 5: return launch16s_one<128, 128, 4, 2, 4, EPI, OUT>(a, s);
+            case 6: return launch16s_one<128, 192, 4, 2, 2, EPI, OUT>(a, s);
+            case 7: return launch16s_one<256, 128, 4, 2, 3, EPI, OUT>(a, s);
             default: break;
         }
-        if (a.N <= 64) return launch16s_one<256, 64, 8, 1, 3, EPI, OUT_S32>(a, s);      // narrow outputs (down conv 1)
+        if (a.N <= 64) return launch16s_one<256, 64, 8, 1, 3, EPI, OUT>(a, s);      // narrow outputs (down conv 1)
         // one 8-wave workgroup per CU (256 slots): 128x192 unless its last round would be mostly idle
         const long tm = (a.M + 127) / 128;
         auto cost = [&](int bn, double eff) {
             const long t = tm * ((a.N + bn - 1) / bn) * a.nz;
             return std::ceil((double)t / 256.0) * bn / eff;
         };
-        if (cost(128, 0.92) < cost(192, 1.0)) return launch16s_one<128, 128, 4, 2, 3, EPI, OUT_S32>(a, s);
-        return launch16s_one<128, 192, 4, 2, 3, EPI, OUT_S32>(a, s);
+        if (cost(128, 0.92) < cost(192, 1.0)) return launch16s_one<128, 128, 4, 2, 3, EPI, OUT>(a, s);
+        return launch16s_one<128, 192, 4, 2, 3, EPI, OUT>(a, s);
     }
 }
 
+int gemm16s_vq_parts(int N) { return ((N + 191) / 192) * 2; }      // (column tiles of 192) x (2 wave columns)
+
 // Contract of launch_gemm16 with both operands in S32: a.A = S32 activations (same strides as the fp32 array),
 // a.W_hi = S32 weights [N][K]; out_s32 selects an S32 C (c_rstride in fp32 elements either way).
-int launch_gemm16s(const GemmArgs& a_in, int epi, int out_s32, hipStream_t s) {
+int launch_gemm16s(const GemmArgs& a_in, int epi, int out, hipStream_t s) {
+    const bool out_s32 = out != OUT_F32;        // some S32 array is written: whole 32-column groups
     const GemmArgs& c = a_in;
     if (c.M <= 0 || c.N <= 0 || c.K <= 0 || c.K % SBK || c.Cin % SBK || c.K != c.taps * c.Cin || c.T_out <= 0 ||
         c.M % c.T_out || c.taps > 32 || !c.W_hi || !c.A || (c.w_rstride % 32) || (c.zW % 32) || (c.a_rstride % 32) ||
@@ -491,13 +537,22 @@ int launch_gemm16s(const GemmArgs& a_in, int epi, int out_s32, hipStream_t s) {
     if (c.pad_mode == PAD_REFLECT && c.Tp < c.T_in) { set_error("gemm16s: reflect Tp < T_in"); return -1; }
     GemmArgs a = a_in;
     a.group_m = (a.N + 191) / 192 > 8 ? 8 : 1;
-#define WT_CASE16S(E, O) if (epi == E && out_s32 == O) return launch16s_tiled<E, O>(a, s);
-    WT_CASE16S(EPI_BIAS, 0)
-    WT_CASE16S(EPI_BIAS, 1)
-    WT_CASE16S(EPI_BIAS_RES, 0)
-    WT_CASE16S(EPI_BIAS_GELU, 1)
-    WT_CASE16S(EPI_BIAS_GAMMA_RES, 0)
-    WT_CASE16S(EPI_HEAD, 1)
+    if ((out == OUT_S32_DUAL_ELU || out == OUT_F32_AND_S32) && !c.C2) { set_error("gemm16s: this output format needs C2"); return -1; }
+    if (epi == EPI_ARGMAX && (!c.vq_xx || !c.vq_ee || !c.vq_pval || !c.vq_pidx || c.vq_nparts != gemm16s_vq_parts(c.N))) {
+        set_error("gemm16s: argmax epilogue needs xx, ee and (value, index) slots for gemm16s_vq_parts(N) parts"); return -1;
+    }
+#define WT_CASE16S(E, O) if (epi == E && out == O) return launch16s_tiled<E, O>(a, s);
+    WT_CASE16S(EPI_BIAS, OUT_F32)
+    WT_CASE16S(EPI_BIAS, OUT_S32)
+    WT_CASE16S(EPI_BIAS, OUT_S32_DUAL_ELU)
+    WT_CASE16S(EPI_BIAS, OUT_F32_AND_S32)
+    WT_CASE16S(EPI_BIAS_RES, OUT_F32)
+    WT_CASE16S(EPI_BIAS_ELU, OUT_S32)
+    WT_CASE16S(EPI_BIAS_RES_ELU, OUT_S32)
+    WT_CASE16S(EPI_BIAS_GELU, OUT_S32)
+    WT_CASE16S(EPI_BIAS_GAMMA_RES, OUT_F32)
+    WT_CASE16S(EPI_HEAD, OUT_S32)
+    WT_CASE16S(EPI_ARGMAX, OUT_F32)
 #undef WT_CASE16S
     set_error("gemm16s: unsupported epilogue / output-format pair");
     return -1;

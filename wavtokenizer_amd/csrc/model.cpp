@@ -476,8 +476,15 @@ static int build_splits(wt_model* M) {
     const int D = a.dim, I = a.intermediate_dim;
     auto conv = [&](const ConvW& c) { return add_split(M, c.w, (long)c.cout * c.k * c.cin); };
     auto conv32 = [&](const ConvW& c) { return (c.cin % 32) ? 0 : add_s32(M, c.w, (long)c.cout * c.k * c.cin); };
-    for (const ResStage& st : M->stages)
-        if (resblock_fusable(st.C)) if (int rc = conv32(st.down)) return rc;     // fed by the S32 output of resblock16
+    for (const ResStage& st : M->stages) {      // encoder chain on S32 operands (build_encode)
+        if (int rc = conv32(st.down)) return rc;
+        if (int rc = conv32(st.c3)) return rc;
+        if (int rc = conv32(st.c1)) return rc;
+        if (int rc = conv32(st.sc)) return rc;
+    }
+    if (int rc = add_s32(M, M->enc_lstm.Wih0, 4L * M->H * M->H)) return rc;
+    if (int rc = conv32(M->enc_final)) return rc;
+    if (int rc = add_s32(M, M->embed, (long)a.vq_bins * 512)) return rc;
     if (int rc = conv32(M->bb_embed)) return rc;
     for (int i = 0; i < 4; ++i) {
         if (int rc = conv32(M->res[i].c1)) return rc;
@@ -635,12 +642,12 @@ static int gemm_auto(const wt_plan* P, const GemmArgs& a, int pro, int epi, hipS
 }
 
 // Both operands pre-split (S32): the activations were written in S32 by their producer, the weight has an S32 copy
-static int gemm_s32(const wt_plan* P, const GemmArgs& a, int epi, int out_s32, hipStream_t s) {
+static int gemm_s32(const wt_plan* P, const GemmArgs& a, int epi, int out, hipStream_t s) {
     auto it = P->model->s32.find(a.W);
     if (it == P->model->s32.end()) { set_error("internal: no S32 copy of this weight"); return WT_ERR_INVALID; }
     GemmArgs b = a;
     b.W_hi = it->second;
-    return launch_gemm16s(b, epi, out_s32, s);
+    return launch_gemm16s(b, epi, out, s);
 }
 // The decoder's dense chain runs on S32 operands unless stage taps are kept (fp32 taps) or fp32 GEMMs are forced
 static bool plan_s32(const wt_plan* P) { return !(P->flags & (WT_PLAN_FLAG_KEEP_STAGES | WT_PLAN_FLAG_FP32_GEMM)); }
@@ -737,9 +744,10 @@ static int plan_resblock(wt_plan* P, const ConvW& c3, const ConvW& c1, const Con
     return y;
 }
 
-// SLSTM (lstm.py:31-39) on x [B][L][H]; returns y = lstm(x) + x
+// SLSTM (lstm.py:31-39) on x [B][L][H]; returns y = lstm(x) + x.  xin_s32 >= 0: an S32 copy of x for the input
+// projection (split-f16 GEMM); y_s32: write y in S32 (its only consumer is a split-f16 conv).
 static int plan_lstm(wt_plan* P, const LstmW& w, int B, int L, int H, int xin, const std::string& name,
-                     bool elu_out = false) {
+                     bool elu_out = false, int xin_s32 = -1, bool y_s32 = false) {
     const int xg = P->buf(name + ".xg", (size_t)B * L * 4 * H);
     const int Bp = (B + 63) / 64 * 64;                            // clip pitch of the K-major hidden state
     const size_t st_numel = (size_t)4 * H * Bp + (size_t)2 * B * H;
@@ -749,8 +757,10 @@ static int plan_lstm(wt_plan* P, const LstmW& w, int B, int L, int H, int xin, c
     // slab: the gather treats a time step as the "clip" (stride H) and the clip as the row (stride L*H)
     GemmArgs ax = linear_args(w.Wih0, w.b0, (long)B * L, 4 * H, H);
     ax.T_in = B; ax.T_out = B; ax.a_bstride = H; ax.a_rstride = (long)L * H;
-    P->step({xin, xg}, [=](const RunCtx& c) {
-        GemmArgs a = ax; a.A = P->ptr(c, xin); a.C = P->ptr(c, xg);
+    const int xsrc = xin_s32 >= 0 ? xin_s32 : xin;
+    P->step({xsrc, xg}, [=](const RunCtx& c) {
+        GemmArgs a = ax; a.A = P->ptr(c, xsrc); a.C = P->ptr(c, xg);
+        if (xin_s32 >= 0) return gemm_s32(P, a, EPI_BIAS, OUT_F32, c.stream);
         return gemm_auto(P, a, PRO_NONE, EPI_BIAS, c.stream);
     });
     P->step({xin, xg, st, y}, [=](const RunCtx& c) {
@@ -760,11 +770,38 @@ static int plan_lstm(wt_plan* P, const LstmW& w, int B, int L, int H, int xin, c
         la.xg0 = P->ptr(c, xg); la.W0 = w.W0; la.W1 = w.W1; la.b1 = w.b1;
         la.h0 = s; la.h1 = s + (size_t)2 * H * Bp; la.c0 = s + (size_t)4 * H * Bp; la.c1 = la.c0 + (size_t)B * H;
         la.x = P->ptr(c, xin); la.y = P->ptr(c, y); la.B = B; la.L = L; la.H = H; la.elu_out = elu_out ? 1 : 0;
+        la.out_s32 = y_s32 ? 1 : 0;
         for (int t = 0; t <= L; ++t)
             if (int rc = launch_lstm_step(la, t, c.stream)) return rc;
         return 0;
     }, L + 2);
     return y;
+}
+
+// Unfused SEANetResnetBlock with every operand pre-split: x arrives as S32(x) (shortcut) and S32(elu(x)) (conv3),
+// the hidden activation and the output are written as S32(elu(.)); returns the output buffer
+static int plan_resblock_s32(wt_plan* P, const ConvW& c3, const ConvW& c1, const ConvW& sc, int B, long T, int x_raw,
+                             int x_elu, const std::string& name) {
+    const int C = sc.cout;
+    const int h = P->buf(name + ".h", (size_t)B * T * (C / 2));
+    const int y = P->buf(name + ".sc", (size_t)B * T * C);
+    const int o = P->buf(name, (size_t)B * T * C);
+    GemmArgs a3 = sconv_args(c3, B, T, 1, 1);
+    P->step({x_elu, h}, [=](const RunCtx& c) {
+        GemmArgs a = a3; a.A = P->ptr(c, x_elu); a.C = P->ptr(c, h);
+        return gemm_s32(P, a, EPI_BIAS_ELU, OUT_S32, c.stream);
+    });
+    GemmArgs as = sconv_args(sc, B, T, 1, 1);
+    P->step({x_raw, y}, [=](const RunCtx& c) {
+        GemmArgs a = as; a.A = P->ptr(c, x_raw); a.C = P->ptr(c, y);
+        return gemm_s32(P, a, EPI_BIAS, OUT_F32, c.stream);
+    });
+    GemmArgs a1 = sconv_args(c1, B, T, 1, 1);
+    P->step({h, y, o}, [=](const RunCtx& c) {
+        GemmArgs a = a1; a.A = P->ptr(c, h); a.C = P->ptr(c, o); a.R = P->ptr(c, y); a.r_rstride = C;
+        return gemm_s32(P, a, EPI_BIAS_RES_ELU, OUT_S32, c.stream);
+    });
+    return o;
 }
 
 static int build_encode(wt_plan* P) {
@@ -787,31 +824,67 @@ static int build_encode(wt_plan* P) {
     const bool fuse_elu = !(P->flags & WT_PLAN_FLAG_KEEP_STAGES);
     long Tc = T;
     int idx = 1;
-    for (const ResStage& st : M->stages) {
-        // fused stages hand their elu'd output to the down conv pre-split (S32): both run on split-f16 MFMAs
-        const bool s32 = plan_s32(P) && resblock_fusable(st.C) && (st.C % 32 == 0) && M->s32.count(st.down.w) != 0;
-        x = plan_resblock(P, st.c3, st.c1, st.sc, B, Tc, x, "enc." + std::to_string(idx), fuse_elu,
-                          (idx == 1 && fold_e0) ? M : nullptr, 0, 0, s32);
+    // S32 mode (default): from the first fused stage on, every GEMM operand of the encoder is written pre-split by
+    // its producer and multiplied by gemm16s.hip; tensors that fp32 kernels read too (fused resblock input, LSTM
+    // skip, embeddings) are written in both forms by the producing GEMM
+    const bool s32 = plan_s32(P);
+    int x_raw = -1, x_elu = -1;          // current stage input as S32(x) and S32(elu(x)) (unfused S32 stages)
+    int x_s32 = -1;                      // S32 copy of the last down conv output (LSTM input projection)
+    for (size_t si = 0; si < M->stages.size(); ++si) {
+        const ResStage& st = M->stages[si];
+        const bool fused = resblock_fusable(st.C) && !(P->flags & WT_PLAN_FLAG_KEEP_STAGES);
+        const bool ws32 = s32 && (st.C % 32 == 0) && M->s32.count(st.down.w) && M->s32.count(st.c3.w) &&
+                          M->s32.count(st.c1.w) && M->s32.count(st.sc.w);
+        bool x_is_s32;                   // the resblock output (elu'd) is S32
+        if (fused) {
+            x = plan_resblock(P, st.c3, st.c1, st.sc, B, Tc, x, "enc." + std::to_string(idx), fuse_elu,
+                              (idx == 1 && fold_e0) ? M : nullptr, 0, 0, ws32);
+            x_is_s32 = ws32;
+        } else if (ws32 && x_raw >= 0) {
+            x = plan_resblock_s32(P, st.c3, st.c1, st.sc, B, Tc, x_raw, x_elu, "enc." + std::to_string(idx));
+            x_is_s32 = true;
+        } else {
+            x = plan_resblock(P, st.c3, st.c1, st.sc, B, Tc, x, "enc." + std::to_string(idx), fuse_elu, nullptr);
+            x_is_s32 = false;
+        }
+        x_raw = x_elu = -1;
         GemmArgs ad = sconv_args(st.down, B, Tc, st.r, 1);
-        const int y = P->buf("enc." + std::to_string(idx + 2), (size_t)B * ad.T_out * st.down.cout);
+        const size_t ynum = (size_t)B * ad.T_out * st.down.cout;
+        const int y = P->buf("enc." + std::to_string(idx + 2), ynum);
         const int xin = x;
-        P->step({xin, y}, [=](const RunCtx& c) {
+        const bool last = si + 1 == M->stages.size();
+        // what the next consumer wants: a fused resblock reads fp32; an unfused S32 stage reads S32 raw + S32 elu; after
+        // the last stage the LSTM reads fp32 (skip) and its input projection S32
+        const bool next_s32_stage = !last && x_is_s32 && (st.down.cout % 32 == 0) &&
+                                    !(resblock_fusable(M->stages[si + 1].C) && !(P->flags & WT_PLAN_FLAG_KEEP_STAGES)) &&
+                                    M->s32.count(M->stages[si + 1].c3.w) && M->s32.count(M->stages[si + 1].sc.w) &&
+                                    M->s32.count(M->stages[si + 1].c1.w) && M->s32.count(M->stages[si + 1].down.w);
+        const bool lstm_s32 = last && x_is_s32 && M->s32.count(M->enc_lstm.Wih0);
+        const int y2 = (next_s32_stage || lstm_s32) ? P->buf("enc." + std::to_string(idx + 2) + ".s32", ynum) : -1;
+        P->step({xin, y, y2}, [=](const RunCtx& c) {
             GemmArgs a = ad; a.A = P->ptr(c, xin); a.C = P->ptr(c, y);
-            if (s32) return gemm_s32(P, a, EPI_BIAS, 0, c.stream);
+            if (y2 >= 0) a.C2 = P->ptr(c, y2);
+            if (x_is_s32)
+                return gemm_s32(P, a, EPI_BIAS, next_s32_stage ? OUT_S32_DUAL_ELU : (lstm_s32 ? OUT_F32_AND_S32 : OUT_F32), c.stream);
             return gemm_auto(P, a, fuse_elu ? PRO_NONE : PRO_ELU, EPI_BIAS, c.stream);
         });
+        if (next_s32_stage) { x_raw = y; x_elu = y2; }
+        if (lstm_s32) x_s32 = y2;
         x = y; Tc = ad.T_out; idx += 3;
     }
     const int L = (int)Tc;
     if (L != P->L) { set_error("internal: frame count mismatch"); return WT_ERR_INVALID; }
     const int H = M->H;
-    x = plan_lstm(P, M->enc_lstm, B, L, H, x, "enc." + std::to_string(idx), fuse_elu);
+    const bool tail_s32 = s32 && x_s32 >= 0 && M->s32.count(M->enc_final.w) && M->s32.count(M->embed);
+    x = plan_lstm(P, M->enc_lstm, B, L, H, x, "enc." + std::to_string(idx), fuse_elu, x_s32, tail_s32);
     GemmArgs af = sconv_args(M->enc_final, B, L, 1, 1);
     const int emb = P->buf("enc." + std::to_string(idx + 2), (size_t)B * L * 512);
+    const int emb_s32 = tail_s32 ? P->buf("enc." + std::to_string(idx + 2) + ".s32", (size_t)B * L * 512) : -1;
     {
         const int xin = x;
-        P->step({xin, emb}, [=](const RunCtx& c) {
+        P->step({xin, emb, emb_s32}, [=](const RunCtx& c) {
             GemmArgs a = af; a.A = P->ptr(c, xin); a.C = P->ptr(c, emb);
+            if (tail_s32) { a.C2 = P->ptr(c, emb_s32); return gemm_s32(P, a, EPI_BIAS, OUT_F32_AND_S32, c.stream); }
             return gemm_auto(P, a, fuse_elu ? PRO_NONE : PRO_ELU, EPI_BIAS, c.stream);
         });
     }
@@ -820,15 +893,17 @@ static int build_encode(wt_plan* P) {
     GemmArgs av = linear_args(M->embed, nullptr, (long)B * L, bins, 512);
     // the argmax epilogue leaves one (value, index) candidate per wave column slab; their number depends on
     // which kernel the distance GEMM runs on
-    const int np = gemm16_covers(P, av, PRO_NONE, EPI_ARGMAX) ? gemm16_vq_parts(bins) : gemm_vq_parts(bins);
+    const int np = tail_s32 ? gemm16s_vq_parts(bins)
+                            : (gemm16_covers(P, av, PRO_NONE, EPI_ARGMAX) ? gemm16_vq_parts(bins) : gemm_vq_parts(bins));
     const int xx = P->buf("vq.xx", (size_t)B * L);
     const int pv = P->buf("vq.pval", (size_t)B * L * np);
     const int pi = P->buf("vq.pidx", (size_t)B * L * np);
     P->step({emb, xx}, [=](const RunCtx& c) { return launch_row_sumsq(P->ptr(c, emb), P->ptr(c, xx), (long)B * L, 512, c.stream); });
-    P->step({emb, xx, pv, pi}, [=](const RunCtx& c) {
-        GemmArgs a = av; a.A = P->ptr(c, emb);
+    P->step({emb, emb_s32, xx, pv, pi}, [=](const RunCtx& c) {
+        GemmArgs a = av; a.A = P->ptr(c, tail_s32 ? emb_s32 : emb);
         a.vq_xx = P->ptr(c, xx); a.vq_ee = M->ee; a.vq_pval = P->ptr(c, pv);
         a.vq_pidx = reinterpret_cast<int*>(P->ptr(c, pi)); a.vq_nparts = np;
+        if (tail_s32) return gemm_s32(P, a, EPI_ARGMAX, OUT_F32, c.stream);
         return gemm_auto(P, a, PRO_NONE, EPI_ARGMAX, c.stream);
     }, 1, "vq.argmin");
     P->step({pv, pi, emb}, [=](const RunCtx& c) {

@@ -639,7 +639,9 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(const LstmAr
     } else {
         a.h1[((long)(t & 1) * H + j) * Bp + cb] = h;
         const float yv = h + x_skip;                    // lstm.py:37-38 skip
-        a.y[((long)cb * L + t) * H + j] = a.elu_out ? (yv > 0.f ? yv : __expf(yv) - 1.f) : yv;
+        const float o = a.elu_out ? (yv > 0.f ? yv : __expf(yv) - 1.f) : yv;
+        if (a.out_s32) store_s32_1(a.y + ((long)cb * L + t) * H, j, o);
+        else a.y[((long)cb * L + t) * H + j] = o;
     }
 }
 
