@@ -133,6 +133,7 @@ struct LstmArgs {
     int B, L, H;
     int elu_out;          // store elu(h1 + x): the only consumer is ELU -> conv (seanet.py:136-139)
     int out_s32;          // write y in the S32 split-f16 layout (its consumer is a gemm16s conv)
+    int f16x3;            // W0 / W1 are the f16 (hi, lo) packings and the state is kept quad-split (ops.hip)
 };
 int launch_lstm_step(const LstmArgs& a, int s, hipStream_t stream);
 struct ResblockArgs {

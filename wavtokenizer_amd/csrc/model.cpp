@@ -32,6 +32,8 @@ struct LstmW {
     float* W0 = nullptr;    // [4H][H]  W_hh_l0 packed
     float* W1 = nullptr;    // [4H][2H] [W_ih_l1 | W_hh_l1] packed
     float* b1 = nullptr;    // [4H]
+    float* W0h = nullptr;   // W0 / W1 as f16 (hi, lo) per-lane packings for the split-f16 step kernel (same bytes)
+    float* W1h = nullptr;
 };
 struct ResStage {
     ConvW c3, c1, sc, down;
@@ -194,6 +196,17 @@ static int load_lstm(wt_model* M, TensorMap& tm, const std::string& prefix, int 
         const int S = k / 16, e = (k % 16) / 4, lk = k % 4;
         dst[blk * 16 * Ktot + (size_t)S * 256 + (size_t)(lk * 16 + li) * 4 + e] = v;
     };
+    // split-f16 packing: per 16 gate rows [K/32][hi, lo][64 lanes][8 halves]: half p of lane (li, lk) in block P is
+    // W[row li][k = 32 P + 16 (p >> 2) + 4 (p & 3) + lk], as hi = f16(w) and lo = f16((w - hi) * 2^11)
+    std::vector<_Float16> W0h((size_t)4 * H * H * 2), W1h((size_t)4 * H * 2 * H * 2);
+    auto put16 = [&](std::vector<_Float16>& dst, size_t prow, int Ktot, int k, float v) {
+        const size_t blk = prow / 16, li = prow % 16;
+        const int P = k / 32, r = k % 32, pp = (r / 16) * 4 + (r % 16) / 4, lk = r % 4;
+        const size_t base = blk * 16 * Ktot * 2 + (size_t)P * 1024 + (size_t)(lk * 16 + li) * 8 + pp;
+        const _Float16 h = (_Float16)v;
+        dst[base] = h;
+        dst[base + 512] = (_Float16)((v - (float)h) * 2048.f);
+    };
     for (int g = 0; g < 4; ++g)
         for (int j = 0; j < H; ++j) {
             const size_t src = (size_t)g * H + j;
@@ -203,6 +216,9 @@ static int load_lstm(wt_model* M, TensorMap& tm, const std::string& prefix, int 
                 put(W0, dst, H, k, whh0[src * H + k]);
                 put(W1, dst, 2 * H, k, wih1[src * H + k]);
                 put(W1, dst, 2 * H, H + k, whh1[src * H + k]);
+                put16(W0h, dst, H, k, whh0[src * H + k]);
+                put16(W1h, dst, 2 * H, k, wih1[src * H + k]);
+                put16(W1h, dst, 2 * H, H + k, whh1[src * H + k]);
             }
             b0[dst] = bih0[src] + bhh0[src];
             b1[dst] = bih1[src] + bhh1[src];
@@ -211,6 +227,13 @@ static int load_lstm(wt_model* M, TensorMap& tm, const std::string& prefix, int 
     if (int rc = upload(M, b0, &out->b0)) return rc;
     if (int rc = upload(M, W0, &out->W0)) return rc;
     if (int rc = upload(M, W1, &out->W1)) return rc;
+    {
+        std::vector<float> t0(W0.size()), t1(W1.size());         // same byte counts: 2 halves per weight
+        std::memcpy(t0.data(), W0h.data(), t0.size() * sizeof(float));
+        std::memcpy(t1.data(), W1h.data(), t1.size() * sizeof(float));
+        if (int rc = upload(M, t0, &out->W0h)) return rc;
+        if (int rc = upload(M, t1, &out->W1h)) return rc;
+    }
     return upload(M, b1, &out->b1);
 }
 
@@ -767,7 +790,8 @@ static int plan_lstm(wt_plan* P, const LstmW& w, int B, int L, int H, int xin, c
         float* s = P->ptr(c, st);
         WT_HIP_CHECK(hipMemsetAsync(s, 0, st_numel * sizeof(float), c.stream));
         LstmArgs la;
-        la.xg0 = P->ptr(c, xg); la.W0 = w.W0; la.W1 = w.W1; la.b1 = w.b1;
+        la.f16x3 = (P->flags & WT_PLAN_FLAG_FP32_GEMM) ? 0 : 1;     // recurrent product on split-f16 MFMAs unless fp32 is forced
+        la.xg0 = P->ptr(c, xg); la.W0 = la.f16x3 ? w.W0h : w.W0; la.W1 = la.f16x3 ? w.W1h : w.W1; la.b1 = w.b1;
         la.h0 = s; la.h1 = s + (size_t)2 * H * Bp; la.c0 = s + (size_t)4 * H * Bp; la.c1 = la.c0 + (size_t)B * H;
         la.x = P->ptr(c, xin); la.y = P->ptr(c, y); la.B = B; la.L = L; la.H = H; la.elu_out = elu_out ? 1 : 0;
         la.out_s32 = y_s32 ? 1 : 0;
@@ -833,8 +857,10 @@ static int build_encode(wt_plan* P) {
     for (size_t si = 0; si < M->stages.size(); ++si) {
         const ResStage& st = M->stages[si];
         const bool fused = resblock_fusable(st.C) && !(P->flags & WT_PLAN_FLAG_KEEP_STAGES);
-        const bool ws32 = s32 && (st.C % 32 == 0) && M->s32.count(st.down.w) && M->s32.count(st.c3.w) &&
-                          M->s32.count(st.c1.w) && M->s32.count(st.sc.w);
+        // a fused stage only needs the S32 down-conv weights (its own convs run inside resblock16); an unfused one
+        // needs S32 copies of all four
+        const bool ws32 = s32 && (st.C % 32 == 0) && M->s32.count(st.down.w) &&
+                          (fused || (M->s32.count(st.c3.w) && M->s32.count(st.c1.w) && M->s32.count(st.sc.w)));
         bool x_is_s32;                   // the resblock output (elu'd) is S32
         if (fused) {
             x = plan_resblock(P, st.c3, st.c1, st.sc, B, Tc, x, "enc." + std::to_string(idx), fuse_elu,

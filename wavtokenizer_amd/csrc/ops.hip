@@ -536,7 +536,17 @@ __device__ __forceinline__ float tanhf_(float x) {
 }
 
 static constexpr int LSTM_WAVES = 16;
+typedef _Float16 f16x8l __attribute__((ext_vector_type(8)));
 
+// F16 = false: v_mfma_f32_16x16x4_f32 on the fp32 state (exact fp32 multiply-add chain).
+// F16 = true : the recurrent product on the f16 matrix pipe with fp32-equivalent products (x = hi + lo * 2^-11,
+//              three v_mfma_f32_16x16x32_f16 per 32-deep block, gemm16.hip): the state is stored pre-split, K-major,
+//              16 bytes per (k, clip quad) = [hi of 4 clips | lo of 4 clips] (same pitch and addresses as the fp32
+//              state), so a lane's load is the same 16 bytes; its 8 loads of a 32-deep block are re-packed in
+//              registers into the A operands of the four clip groups, and the weights arrive packed per lane as
+//              [hi of its 8 k | lo of its 8 k].  The fp32 pipe needs 64 MFMAs x 32 cycles per layer-1 wave and
+//              step, this 24 x 16.
+template <bool F16>
 __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(const LstmArgs a, int s_in) {
     __shared__ float red[LSTM_WAVES][64][17];
     const int s = s_in & 0xffff, dbg = s_in >> 16;     // dbg: timing experiments only (WT_LSTM_DBG)
@@ -555,8 +565,9 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(const LstmAr
     const int Ktot = layer ? 2 * H : H;
     const int kw = Ktot / LSTM_WAVES;               // K slice of this wave: 32 (layer 0) or 64 (layer 1)
     const int kbeg = wave * kw;
-    // packed weights of this workgroup: [Ktot/16][64 lanes][4]: element e of lane (li, lk) in group S is
-    // W[gate row bj*16 + li][k = 16 S + 4 e + lk]
+    // packed weights of this workgroup, 16 bytes per lane and 16 k.  fp32: [Ktot/16][64 lanes][4]: element e of
+    // lane (li, lk) in group S is W[gate row bj*16 + li][k = 16 S + 4 e + lk].  f16: [Ktot/32][hi, lo][64 lanes][8]:
+    // half p of lane (li, lk) in block P is W[row][k = 32 P + 16 (p >> 2) + 4 (p & 3) + lk]
     const float* W = (layer ? a.W1 : a.W0) + (long)bj * 16 * Ktot + (long)(kbeg / 16) * 256 + lane * 4;
     // source of the K slice: layer 0: h0[t-1]; layer 1: [h0[t] | h1[t-1]]   (each [H][Bp], K-major)
     const float* hsrc;
@@ -587,7 +598,7 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(const LstmAr
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] = (f32x4acc){0.f, 0.f, 0.f, 0.f};
     f32x4 wv[4], hv[16];
-    const int nS = kw / 16;                         // weight groups: 2 or 4; k-steps: 4 per group
+    const int nS = kw / 16;                         // 16-k groups: 2 or 4; k-steps: 4 per group
 #pragma unroll
     for (int S = 0; S < 4; ++S) {
         if (S < nS) {
@@ -602,15 +613,43 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(const LstmAr
             for (int q = 0; q < 4; ++q) hv[4 * S + q] = *reinterpret_cast<const f32x4*>(hp + (long)(4 * (4 * S + q)) * Bp);
         }
     }
+    if constexpr (!F16) {
 #pragma unroll
-    for (int S = 0; S < 4; ++S) {
-        if (S < nS) {
+        for (int S = 0; S < 4; ++S) {
+            if (S < nS) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)         // MFMA row r <-> clip 4 r + e; k = 16 S + 4 q + lk
-                    acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[4 * S + q][e], wv[S][q], acc[e], 0, 0, 0);
+                    for (int e = 0; e < 4; ++e)         // MFMA row r <-> clip 4 r + e; k = 16 S + 4 q + lk
+                        acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[4 * S + q][e], wv[S][q], acc[e], 0, 0, 0);
+            }
         }
+    } else {
+        f32x4acc accc[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) accc[e] = (f32x4acc){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int P = 0; P < 2; ++P) {
+            if (2 * P < nS) {
+                // weights of block P: wv[2P] = hi halves of the lane's 8 k, wv[2P+1] = lo halves
+                const f16x8l wh = __builtin_bit_cast(f16x8l, wv[2 * P]), wl = __builtin_bit_cast(f16x8l, wv[2 * P + 1]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {           // clip group e: half e (hi) / 4 + e (lo) of the 8 loaded quads
+                    f16x8l ah, al;
+#pragma unroll
+                    for (int pq = 0; pq < 8; ++pq) {
+                        const f16x8l v = __builtin_bit_cast(f16x8l, hv[8 * P + pq]);
+                        ah[pq] = v[e];
+                        al[pq] = v[4 + e];
+                    }
+                    acc[e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh, acc[e], 0, 0, 0);
+                    accc[e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl, accc[e], 0, 0, 0);
+                    accc[e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh, accc[e], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = acc[e] + accc[e] * (1.f / 2048.f);
     }
     // C layout 16x16: col = lane & 15 (gate row), row = 4*(lane>>4) + reg  ->  clip 4 row + e
 #pragma unroll
@@ -634,10 +673,17 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(const LstmAr
     const float c = fg * c_prev + ig * gg;
     const float h = og * tanhf_(c);
     *cst = c;
-    if (!layer) {
-        a.h0[((long)(t & 1) * H + j) * Bp + cb] = h;
+    float* hdst = (layer ? a.h1 : a.h0) + (long)(t & 1) * H * Bp;
+    if constexpr (F16) {
+        // quad-split state: 16 bytes per (k, clip quad) = [hi x 4 | lo x 4]
+        _Float16* hq = reinterpret_cast<_Float16*>(hdst) + ((long)j * Bp + (cb & ~3)) * 2 + (cb & 3);
+        const _Float16 hh = (_Float16)h;
+        hq[0] = hh;
+        hq[4] = (_Float16)((h - (float)hh) * 2048.f);
     } else {
-        a.h1[((long)(t & 1) * H + j) * Bp + cb] = h;
+        hdst[(long)j * Bp + cb] = h;
+    }
+    if (layer) {
         const float yv = h + x_skip;                    // lstm.py:37-38 skip
         const float o = a.elu_out ? (yv > 0.f ? yv : __expf(yv) - 1.f) : yv;
         if (a.out_s32) store_s32_1(a.y + ((long)cb * L + t) * H, j, o);
@@ -651,7 +697,8 @@ int launch_lstm_step(const LstmArgs& a, int s, hipStream_t stream) {
     dim3 grid(2 * (a.H / 4), (a.B + 63) / 64);
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("WT_LSTM_DBG"); dbg = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(64 * LSTM_WAVES), 0, stream, a, s | (dbg << 16));
+    if (a.f16x3) hipLaunchKernelGGL(lstm_step_kernel<true>, grid, dim3(64 * LSTM_WAVES), 0, stream, a, s | (dbg << 16));
+    else hipLaunchKernelGGL(lstm_step_kernel<false>, grid, dim3(64 * LSTM_WAVES), 0, stream, a, s | (dbg << 16));
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }
