@@ -165,6 +165,29 @@ size_t wt_vq_workspace_bytes(int64_t N, int32_t bins);
 int wt_vq_nearest(const float* x, const float* embed, int64_t N, int32_t D, int32_t bins, int64_t* codes_out,
                   void* workspace, void* stream);
 
+/* ---- helpers on either side of the hot path ------------------------------------- */
+
+/* Replaces: convert_audio (encoder/utils.py:79-92) with target_channels = 1: mean over the C (1 or 2) channels, then
+ * torchaudio.transforms.Resample(orig_sr, new_sr) (sinc_interp_hann, lowpass_filter_width 6, rolloff 0.99; torchaudio
+ * is not in this image: restated from its published algorithm, parity unpinned).  wav [B][C][T] -> out [B][T'],
+ * T' = wt_resampler_out_length(T) = ceil(new * T / orig).  Equal rates give the plain channel mean. */
+typedef struct wt_resampler wt_resampler;
+int     wt_resampler_create(int32_t orig_sr, int32_t new_sr, int32_t device, wt_resampler** out);
+void    wt_resampler_destroy(wt_resampler* r);
+int64_t wt_resampler_out_length(const wt_resampler* r, int64_t T);
+int     wt_convert_audio(const wt_resampler* r, const float* wav, int32_t B, int32_t C, int64_t T, float* out, void* stream);
+
+/* Replaces: save_audio's clamp / rescale (encoder/utils.py:95-103) + the PCM_S 16 conversion of torchaudio.save
+ * (infer.py:70): rescale = 0: clamp to [-limit, limit]; 1: scale by min(limit / max|x|, 1) (workspace: 4 bytes);
+ * then round-half-even(x * 32768) clipped to int16 (the backend's rounding rule is not pinned by the reference). */
+int wt_pcm16(const float* x, int64_t n, float limit, int32_t rescale, int16_t* out, void* workspace, void* stream);
+
+/* Replaces: _linear_overlap_add (encoder/utils.py:17-56), bit for bit: frames [n_frames][rows][frame_len] (the last
+ * one holds last_len valid samples), weight [frame_len] = the reference's triangle 0.5 - |linspace(0,1,len+2)[1:-1] - 0.5|,
+ * out [rows][stride * (n_frames - 1) + last_len]. */
+int wt_linear_overlap_add(const float* frames, const float* weight, int32_t n_frames, int64_t rows, int64_t frame_len,
+                          int64_t last_len, int64_t stride, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

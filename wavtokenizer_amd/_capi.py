@@ -19,6 +19,8 @@ EXPORTS = [
     "wt_plan_find_buffer", "wt_plan_buffer_name", "wt_plan_num_steps", "wt_plan_step_name", "wt_plan_set_timing",
     "wt_plan_read_timing", "wt_encode", "wt_codes_to_features", "wt_decode",
     "wt_seanet_decode", "wt_sconv1d", "wt_linear", "wt_conv1d_s32", "wt_vq_workspace_bytes", "wt_vq_nearest",
+    "wt_resampler_create", "wt_resampler_destroy", "wt_resampler_out_length", "wt_convert_audio", "wt_pcm16",
+    "wt_linear_overlap_add",
 ]
 
 WT_PLAN_ENCODE, WT_PLAN_DECODE, WT_PLAN_SEANET_DECODER = 0, 1, 2
@@ -81,6 +83,14 @@ def _load() -> ctypes.CDLL:
     lib.wt_vq_workspace_bytes.argtypes = [c_int64, c_int32]
     lib.wt_vq_workspace_bytes.restype = c_size_t
     lib.wt_vq_nearest.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
+    lib.wt_resampler_create.argtypes = [c_int32, c_int32, c_int32, POINTER(c_void_p)]
+    lib.wt_resampler_destroy.argtypes = [c_void_p]
+    lib.wt_resampler_destroy.restype = None
+    lib.wt_resampler_out_length.argtypes = [c_void_p, c_int64]
+    lib.wt_resampler_out_length.restype = c_int64
+    lib.wt_convert_audio.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p, c_void_p]
+    lib.wt_pcm16.argtypes = [c_void_p, c_int64, ctypes.c_float, c_int32, c_void_p, c_void_p, c_void_p]
+    lib.wt_linear_overlap_add.argtypes = [c_void_p, c_void_p, c_int32, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]
     return lib
 
 
