@@ -396,7 +396,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
                     const int n = n_w + j * 32 + 8 * g + col_h;        // columns n .. n+3 (N % 4 == 0)
                     if (n >= p.N) continue;
                     f32x4 v = acc4(i, j, g);
-                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                    if (EPI == EPI_SCALE || EPI == EPI_BIAS_ROW) {
+                        v = EPI == EPI_SCALE ? v * p.alpha : v + p.bias[m];
+                        // these two take any N: the columns of a partial last run are written as zeros (pad columns
+                        // of the row pitch, which the consumers rely on being zero)
+                        if (n + 3 >= p.N) { if (n + 1 >= p.N) v.y = 0.f; if (n + 2 >= p.N) v.z = 0.f; v.w = 0.f; }
+                    }
+                    else if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
                     if (EPI == EPI_BIAS_RES) {
                         v = v + *reinterpret_cast<const f32x4*>(p.R + (long)m * p.r_rstride + n);
                     } else if (EPI == EPI_BIAS_RES_ELU) {
@@ -520,7 +526,7 @@ int launch_gemm16s(const GemmArgs& a_in, int epi, int out, hipStream_t s) {
     const GemmArgs& c = a_in;
     if (c.M <= 0 || c.N <= 0 || c.K <= 0 || c.K % SBK || c.Cin % SBK || c.K != c.taps * c.Cin || c.T_out <= 0 ||
         c.M % c.T_out || c.taps > 32 || !c.W_hi || !c.A || (c.w_rstride % 32) || (c.zW % 32) || (c.a_rstride % 32) ||
-        (c.a_bstride % 32) || (c.zA % 32) || (c.N % 4) || (c.c_rstride % 4) || (c.zC % 4) || (c.r_rstride % 4) || (out_s32 && ((c.c_rstride % 32) || (c.zC % 32) || (c.N % 32)))) {
+        (c.a_bstride % 32) || (c.zA % 32) || ((c.N % 4) && !((epi == EPI_SCALE || epi == EPI_BIAS_ROW) && c.c_rstride >= ((c.N + 3) & ~3))) || (c.c_rstride % 4) || (c.zC % 4) || (c.r_rstride % 4) || (out_s32 && ((c.c_rstride % 32) || (c.zC % 32)))) {
         set_error("gemm16s: unsupported problem (S32 operands need every extent and stride in multiples of 32)");
         return -1;
     }
@@ -553,6 +559,8 @@ int launch_gemm16s(const GemmArgs& a_in, int epi, int out, hipStream_t s) {
     WT_CASE16S(EPI_BIAS_GAMMA_RES, OUT_F32)
     WT_CASE16S(EPI_HEAD, OUT_S32)
     WT_CASE16S(EPI_ARGMAX, OUT_F32)
+    WT_CASE16S(EPI_SCALE, OUT_F32)
+    WT_CASE16S(EPI_BIAS_ROW, OUT_S32)
 #undef WT_CASE16S
     set_error("gemm16s: unsupported epilogue / output-format pair");
     return -1;

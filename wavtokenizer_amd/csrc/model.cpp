@@ -519,6 +519,9 @@ static int build_splits(wt_model* M) {
     }
     if (int rc = add_s32(M, M->head_W, 2L * M->Kb * D)) return rc;
     if (int rc = add_s32(M, M->istft_W, 4L * M->Kq * M->Kq)) return rc;
+    if (int rc = add_s32(M, M->at_Wqk, 2L * D * D)) return rc;
+    if (int rc = add_s32(M, M->at_Wv, (long)D * D)) return rc;
+    if (int rc = add_s32(M, M->at_Wp, (long)D * D)) return rc;
     for (const ResStage& st : M->stages) {
         if (int rc = conv(st.down)) return rc;
         if (int rc = conv(st.sc)) return rc;
@@ -999,6 +1002,52 @@ static int build_decode(wt_plan* P) {
     };
     resnet(M->res[0], "bb.pos_net.0");
     resnet(M->res[1], "bb.pos_net.1");
+    if (s32 && M->s32.count(M->at_Wqk) && M->s32.count(M->at_Wv) && M->s32.count(M->at_Wp)) {
+        // AttnBlock (models.py:107-127), single head of width D, every product on split-f16 MFMAs: the normalised
+        // input, q | k, V^T, the probabilities and the attention output are all written pre-split by their producers
+        const int qk = P->buf("bb.attn.qk", (size_t)Mrows * 2 * D);          // S32 [M][q | k]
+        const int vt = P->buf("bb.attn.vt", (size_t)B * D * Lp);              // S32 [B][D][Lp]
+        const int S = P->buf("bb.attn.s", (size_t)Mrows * Lp);                // fp32 scores
+        const int Ps = P->buf("bb.attn.p", (size_t)Mrows * Lp);               // S32 probabilities
+        const int o = P->buf("bb.attn.o", (size_t)Mrows * D);                 // S32
+        P->step({x, sc, sh, h1}, [=](const RunCtx& c) {
+            return launch_gn_apply(P->ptr(c, x), M->at_nw, M->at_nb, P->ptr(c, sc), P->ptr(c, sh), P->ptr(c, h1), 0, B, L, D, 32, 1e-6f, c.stream, 1);
+        }, 1, "attn.gn");
+        GemmArgs aqk = linear_args(M->at_Wqk, M->at_bqk, Mrows, 2 * D, D);
+        P->step({h1, qk}, [=](const RunCtx& c) {
+            GemmArgs a = aqk; a.A = P->ptr(c, h1); a.C = P->ptr(c, qk);
+            return gemm_s32(P, a, EPI_BIAS, OUT_S32, c.stream);
+        }, 1, "attn.qk");
+        P->step({h1, vt}, [=](const RunCtx& c) {     // V^T[b] = Wv . hn[b]^T + bv   (D x L, pitch Lp; pad columns stay zero)
+            WT_HIP_CHECK(hipMemsetAsync(P->ptr(c, vt), 0, (size_t)B * D * Lp * sizeof(float), c.stream));
+            GemmArgs a = linear_args(P->ptr(c, h1), M->at_bv, D, L, D);
+            a.A = reinterpret_cast<const float*>(M->s32.at(M->at_Wv)); a.zA = 0;
+            a.W_hi = P->ptr(c, h1); a.zW = (long)L * D; a.nz = B;
+            a.C = P->ptr(c, vt); a.c_rstride = Lp; a.zC = (long)D * Lp;
+            return launch_gemm16s(a, EPI_BIAS_ROW, OUT_S32, c.stream);
+        }, 2, "attn.vt");
+        P->step({qk, S}, [=](const RunCtx& c) {      // S[b] = q[b] . k[b]^T * D^-0.5
+            GemmArgs a = linear_args(nullptr, nullptr, L, L, D);
+            a.A = P->ptr(c, qk); a.a_rstride = 2 * D; a.zA = (long)L * 2 * D;
+            a.W_hi = P->ptr(c, qk) + D; a.w_rstride = 2 * D; a.zW = (long)L * 2 * D; a.nz = B;
+            a.C = P->ptr(c, S); a.c_rstride = Lp; a.zC = (long)L * Lp;
+            a.alpha = (float)std::pow((double)D, -0.5);
+            return launch_gemm16s(a, EPI_SCALE, OUT_F32, c.stream);
+        }, 1, "attn.s");
+        P->step({S, Ps}, [=](const RunCtx& c) { return launch_softmax(P->ptr(c, S), (int)Mrows, L, Lp, c.stream, P->ptr(c, Ps)); });
+        P->step({Ps, vt, o}, [=](const RunCtx& c) {  // O[b] = P[b] . V[b]
+            GemmArgs a = linear_args(nullptr, nullptr, L, D, Lp);
+            a.A = P->ptr(c, Ps); a.zA = (long)L * Lp;
+            a.W_hi = P->ptr(c, vt); a.zW = (long)D * Lp; a.nz = B;
+            a.C = P->ptr(c, o); a.c_rstride = D; a.zC = (long)L * D;
+            return launch_gemm16s(a, EPI_BIAS, OUT_S32, c.stream);
+        }, 1, "attn.o");
+        GemmArgs ap = linear_args(M->at_Wp, M->at_bp, Mrows, D, D);
+        P->step({o, x}, [=](const RunCtx& c) {
+            GemmArgs a = ap; a.A = P->ptr(c, o); a.C = P->ptr(c, x); a.R = P->ptr(c, x); a.r_rstride = D;
+            return gemm_s32(P, a, EPI_BIAS_RES, OUT_F32, c.stream);
+        }, 1, "attn.proj");
+    } else
     {   // AttnBlock (models.py:107-127), single head of width D
         const int qk = P->buf("bb.attn.qk", (size_t)Mrows * 2 * D);
         const int vt = P->buf("bb.attn.vt", (size_t)B * D * Lp);

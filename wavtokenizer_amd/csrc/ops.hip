@@ -233,9 +233,102 @@ int launch_gn_stats(const float* x, const float* gamma, const float* beta, float
     return 0;
 }
 
+// GroupNorm apply for short sequences: a block owns GB groups (a 384-byte channel slab for C/32 = 24, GB = 4) of one
+// clip, pulls the L x (GB*cg) slab into LDS with full-line loads, takes mean and variance from LDS (two-pass, one
+// wave per group), and writes the normalised (swish-activated) slab back once, fp32 or S32: one global read and one
+// write per element where gn_stats_kernel makes three strided read passes.
+template <int SWISH>
+__global__ __launch_bounds__(256) void gn_tile_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ scale,
+                                                      float* __restrict__ shift, float* __restrict__ y, int L, int C,
+                                                      int cg, int GB, float eps, int s32) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];      // [L][W], W = GB * cg
+    __shared__ float s_sc[128], s_sh[128];
+    const int W = GB * cg, W4 = W / 4;
+    const int c0 = blockIdx.x * W, b = blockIdx.y;
+    const float* xb = x + (long)b * L * C + c0;
+    // (row, float4) of element e = threadIdx.x + 256 k, advanced without divisions
+    const int dt = 256 / W4, dq = 256 - dt * W4;
+    {
+        int t = threadIdx.x / W4, q = threadIdx.x - t * W4;
+        for (; t < L; t += dt, q += dq) {
+            if (q >= W4) { q -= W4; ++t; if (t >= L) break; }
+            *reinterpret_cast<f32x4*>(tile + t * W + q * 4) = *reinterpret_cast<const f32x4*>(xb + (long)t * C + q * 4);
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int st = 64 / cg, sj = 64 - st * cg;               // lane stride 64 in (row, channel) steps
+    for (int gl = wv; gl < GB; gl += 4) {                  // one wave per group
+        const int n = L * cg;
+        const float* col = tile + gl * cg;
+        float sum = 0.f;
+        {
+            int t = lane / cg, j = lane - t * cg;
+            for (; t < L; t += st, j += sj) {
+                if (j >= cg) { j -= cg; ++t; if (t >= L) break; }
+                sum += col[t * W + j];
+            }
+        }
+        const float mean = wave_sum(sum) / (float)n;
+        float sq = 0.f;
+        {
+            int t = lane / cg, j = lane - t * cg;
+            for (; t < L; t += st, j += sj) {
+                if (j >= cg) { j -= cg; ++t; if (t >= L) break; }
+                const float d = col[t * W + j] - mean;
+                sq += d * d;
+            }
+        }
+        const float rstd = 1.f / sqrtf(wave_sum(sq) / (float)n + eps);
+        if (lane < cg) {
+            const int c = c0 + gl * cg + lane;
+            const float sc = rstd * gamma[c], sh = beta[c] - mean * sc;
+            s_sc[gl * cg + lane] = sc; s_sh[gl * cg + lane] = sh;
+            scale[(long)b * C + c] = sc; shift[(long)b * C + c] = sh;
+        }
+    }
+    __syncthreads();
+    float* yb = y + (long)b * L * C;
+    {
+        int t = threadIdx.x / W4, q = threadIdx.x - t * W4;
+        for (; t < L; t += dt, q += dq) {
+            if (q >= W4) { q -= W4; ++t; if (t >= L) break; }
+            const f32x4 v = *reinterpret_cast<const f32x4*>(tile + t * W + q * 4);
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(s_sc + q * 4), sh = *reinterpret_cast<const f32x4*>(s_sh + q * 4);
+            f32x4 o = v * sc + sh;
+            if (SWISH) {     // x * sigmoid(x) on the hardware exp / rcp (relative error ~1e-7)
+                o.x *= __builtin_amdgcn_rcpf(1.f + __expf(-o.x)); o.y *= __builtin_amdgcn_rcpf(1.f + __expf(-o.y));
+                o.z *= __builtin_amdgcn_rcpf(1.f + __expf(-o.z)); o.w *= __builtin_amdgcn_rcpf(1.f + __expf(-o.w));
+            }
+            if (s32) store_s32_4(yb + (long)t * C, c0 + q * 4, o);
+            else *reinterpret_cast<f32x4*>(yb + (long)t * C + c0 + q * 4) = o;
+        }
+    }
+}
+
 int launch_gn_apply(const float* x, const float* gamma, const float* beta, float* scale, float* shift, float* y,
                     int swish, int B, int L, int C, int groups, float eps, hipStream_t s, int out_s32) {
     if (out_s32 && (C % 32)) { set_error("gn_apply: an S32 output needs C % 32 == 0"); return -1; }
+    const int cg = C / groups;
+    // slab kernel: GB groups = a multiple of 32 channels (whole S32 groups, 16-byte rows), slab within the LDS budget
+    int GB = 0;
+    for (int g = 1; g <= groups; ++g)
+        if (groups % g == 0 && (g * cg) % 32 == 0 && g * cg <= 128) { GB = g; break; }
+    if (GB && (cg % 4 == 0) && (size_t)L * GB * cg * 4 <= 96 * 1024 && (C % 4 == 0)) {
+        const size_t smem = (size_t)L * GB * cg * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gn_tile_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gn_tile_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            attr_set = true;
+        }
+        dim3 grid(groups / GB, B);
+        if (swish) hipLaunchKernelGGL(gn_tile_kernel<1>, grid, dim3(256), smem, s, x, gamma, beta, scale, shift, y, L, C, cg, GB, eps, out_s32);
+        else hipLaunchKernelGGL(gn_tile_kernel<0>, grid, dim3(256), smem, s, x, gamma, beta, scale, shift, y, L, C, cg, GB, eps, out_s32);
+        WT_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (swish)
         hipLaunchKernelGGL(gn_stats_kernel<2>, dim3(groups, B), dim3(256), 0, s, x, gamma, beta, scale, shift, y, L, C,
                            C / groups, eps, out_s32);
@@ -344,7 +437,7 @@ int launch_rownorm(int mode, const float* x, float* y, int B, int L, int C, cons
 // -------------------------------------------------------------------------------------- softmax
 // AttnBlock softmax over keys (decoder/models.py:119); one wave per query row; pad columns
 // [L, ld) are zero-filled so the P.V contraction can run over the padded length.
-__global__ __launch_bounds__(256) void softmax_kernel(float* __restrict__ S, long rows, int L, int ld) {
+__global__ __launch_bounds__(256) void softmax_kernel(float* __restrict__ S, long rows, int L, int ld, float* __restrict__ P_s32) {
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
@@ -359,11 +452,16 @@ __global__ __launch_bounds__(256) void softmax_kernel(float* __restrict__ S, lon
         sum += e;
     }
     sum = wave_sum(sum);
-    for (int j = lane; j < ld; j += 64) row[j] = j < L ? row[j] / sum : 0.f;
+    if (P_s32) {        // probabilities for a split-f16 GEMM: S32 rows in a separate buffer (pad columns zero)
+        for (int j = lane; j < ld; j += 64) store_s32_1(P_s32 + r * ld, j, j < L ? row[j] / sum : 0.f);
+    } else {
+        for (int j = lane; j < ld; j += 64) row[j] = j < L ? row[j] / sum : 0.f;
+    }
 }
 
-int launch_softmax(float* S, int rows, int L, int ld, hipStream_t s) {
-    hipLaunchKernelGGL(softmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, S, (long)rows, L, ld);
+int launch_softmax(float* S, int rows, int L, int ld, hipStream_t s, float* P_s32) {
+    if (P_s32 && (ld % 32)) { set_error("softmax: an S32 output needs a row pitch in multiples of 32"); return -1; }
+    hipLaunchKernelGGL(softmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, S, (long)rows, L, ld, P_s32);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }
