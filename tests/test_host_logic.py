@@ -191,3 +191,22 @@ def test_from_pretrained0911_averages_best_three(tmp_path):
     picked = sorted((n for n in losses if n.startswith("vocos_")), key=lambda n: n[-11:-5])[:3]
     want = sum(sds[n][key] for n in picked) / 3
     assert torch.allclose(m.state_dict()[key], want, rtol=1e-6, atol=1e-9), (best, picked)
+
+
+def test_packed_weights_round_trip(tmp_path):
+    """save_packed / from_packed: one safetensors file with exactly the hot-path keys, nothing
+    executed on load, values bit-identical."""
+    from safetensors import safe_open
+    from wavtokenizer_amd import WavTokenizer
+    cfg = _yaml_for("hop600", tmp_path)
+    sd = _fake_lightning_ckpt(str(tmp_path / "m.ckpt"), "hop600")
+    m = WavTokenizer.from_pretrained0802(cfg, str(tmp_path / "m.ckpt"))
+    path = str(tmp_path / "hot_path.safetensors")
+    m.save_packed(path)
+    with safe_open(path, framework="pt") as f:
+        assert set(f.keys()) == set(m.state_dict().keys()) and len(list(f.keys())) == 289
+        assert f.metadata()["format"] == "wavtokenizer_amd.packed.v1"
+    m2 = WavTokenizer.from_packed(cfg, path)
+    assert not m2.training
+    for k, v in m.state_dict().items():
+        assert torch.equal(m2.state_dict()[k], v), k

@@ -294,6 +294,24 @@ class WavTokenizer(nn.Module):
         model.eval()
         return model
 
+    # -- packed weights: one pickle-free file holding exactly the hot-path tensors ---------------------------------
+    def save_packed(self, path: str) -> None:
+        """Write the hot-path state (the 289 reference keys this class keeps; discriminators, optimizer state and
+        the rest of a Lightning checkpoint are gone) as one safetensors file: nothing is executed when it is read
+        back, and it loads without unpickling a multi-GB training checkpoint."""
+        from safetensors.torch import save_file
+        sd = {k: v.detach().to("cpu", copy=True).contiguous() for k, v in self.state_dict().items()}
+        save_file(sd, path, metadata={"format": "wavtokenizer_amd.packed.v1", "hop": str(self._arch.hop)})
+
+    @classmethod
+    def from_packed(cls, config_path: str, packed_path: str) -> "WavTokenizer":
+        """Counterpart of from_pretrained0802 (pretrained.py:95-114) for a file written by save_packed."""
+        from safetensors.torch import load_file
+        model = cls.from_hparams0802(config_path)
+        model.load_state_dict(load_file(packed_path, device="cpu"))
+        model.eval()
+        return model
+
     @classmethod
     def from_pretrained(cls, repo_id: str) -> "WavTokenizer":
         from huggingface_hub import hf_hub_download
