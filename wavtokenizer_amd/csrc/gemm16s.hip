@@ -574,7 +574,7 @@ static int launch16s_tiled(const GemmArgs& a, hipStream_t s) {
             const long t = tm * ((a.N + bn - 1) / bn) * a.nz;
             return std::ceil((double)t / 256.0) * bn / eff;
         };
-        if (cost(128, 0.92) < cost(192, 1.0)) return launch16s_one<128, 128, 4, 2, 3, EPI, OUT>(a, s);
+        if (cost(128, 0.82) < cost(192, 1.0)) return launch16s_one<128, 128, 4, 2, 3, EPI, OUT>(a, s);
         return launch16s_one<128, 192, 4, 2, 3, EPI, OUT>(a, s);
     }
 }
