@@ -634,6 +634,7 @@ __device__ __forceinline__ float tanhf_(float x) {
 }
 
 static constexpr int LSTM_WAVES = 16;
+static constexpr int LSTM_MAXS = 64 / LSTM_WAVES;     // 16-k groups per wave of the widest (layer-1, K = 1024) slice
 typedef _Float16 f16x8l __attribute__((ext_vector_type(8)));
 
 // F16 = false: v_mfma_f32_16x16x4_f32 on the fp32 state (exact fp32 multiply-add chain).
@@ -661,7 +662,7 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(const LstmAr
     const int li = lane & 15, lk = lane >> 4;
 
     const int Ktot = layer ? 2 * H : H;
-    const int kw = Ktot / LSTM_WAVES;               // K slice of this wave: 32 (layer 0) or 64 (layer 1)
+    const int kw = Ktot / LSTM_WAVES;               // K slice of this wave (16 waves: 32 / 64; 8 waves: 64 / 128)
     const int kbeg = wave * kw;
     // packed weights of this workgroup, 16 bytes per lane and 16 k.  fp32: [Ktot/16][64 lanes][4]: element e of
     // lane (li, lk) in group S is W[gate row bj*16 + li][k = 16 S + 4 e + lk].  f16: [Ktot/32][hi, lo][64 lanes][8]:
@@ -695,10 +696,10 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(const LstmAr
     f32x4acc acc[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] = (f32x4acc){0.f, 0.f, 0.f, 0.f};
-    f32x4 wv[4], hv[16];
+    f32x4 wv[LSTM_MAXS], hv[4 * LSTM_MAXS];
     const int nS = kw / 16;                         // 16-k groups: 2 or 4; k-steps: 4 per group
 #pragma unroll
-    for (int S = 0; S < 4; ++S) {
+    for (int S = 0; S < LSTM_MAXS; ++S) {
         if (S < nS) {
             if (dbg & 2) {
                 wv[S] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -713,7 +714,7 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(const LstmAr
     }
     if constexpr (!F16) {
 #pragma unroll
-        for (int S = 0; S < 4; ++S) {
+        for (int S = 0; S < LSTM_MAXS; ++S) {
             if (S < nS) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -727,7 +728,7 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(const LstmAr
 #pragma unroll
         for (int e = 0; e < 4; ++e) accc[e] = (f32x4acc){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int P = 0; P < 2; ++P) {
+        for (int P = 0; P < LSTM_MAXS / 2; ++P) {
             if (2 * P < nS) {
                 // weights of block P: wv[2P] = hi halves of the lane's 8 k, wv[2P+1] = lo halves
                 const f16x8l wh = __builtin_bit_cast(f16x8l, wv[2 * P]), wl = __builtin_bit_cast(f16x8l, wv[2 * P + 1]);
