@@ -406,13 +406,85 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
     }
 }
 
+// RN_DWCONV with each wave producing R consecutive frames of one clip: the R + 6 input rows and the 7 tap rows are
+// loaded once per 256-channel slice instead of once per output frame (7 row loads + 7 tap loads per frame before).
+// Same accumulation order per output as rownorm_kernel, so the results are identical.
+template <int NV, int R>
+__global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int L,
+                                                        const float* __restrict__ dw_w, const float* __restrict__ dw_b,
+                                                        const float* __restrict__ out_scale,
+                                                        const float* __restrict__ out_shift, float eps, int s32) {
+    constexpr int C = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int per_clip = (L + R - 1) / R;
+    const long wq = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wq >= (long)B * per_clip) return;
+    const int b = (int)(wq / per_clip);
+    const int t0 = (int)(wq - (long)b * per_clip) * R;
+    const float* xb = x + (long)b * L * C;
+    f32x4 v[R][NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        f32x4 xr[R + 6], w[7];
+#pragma unroll
+        for (int k = 0; k < R + 6; ++k) {
+            const int tt = t0 + k - 3;
+            xr[k] = (tt >= 0 && tt < L) ? *reinterpret_cast<const f32x4*>(xb + (long)tt * C + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < 7; ++j) w[j] = *reinterpret_cast<const f32x4*>(dw_w + j * C + c);
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(dw_b + c);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            f32x4 acc = bias;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int tt = t0 + r + j - 3;
+                if (tt >= 0 && tt < L) acc += xr[r + j] * w[j];
+            }
+            v[r][i] = acc;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (t0 + r >= L) break;
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) sum += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w);
+        const float mean = wave_sum(sum) * (1.f / C);
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const f32x4 d = v[r][i] - mean;
+            sq += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+        }
+        const float rstd = 1.f / sqrtf(wave_sum(sq) * (1.f / C) + eps);
+        float* yrow = y + ((long)b * L + t0 + r) * C;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            const f32x4 os = *reinterpret_cast<const f32x4*>(out_scale + c);
+            const f32x4 oh = *reinterpret_cast<const f32x4*>(out_shift + c);
+            const f32x4 o = ((v[r][i] - mean) * rstd) * os + oh;
+            if (s32) store_s32_4(yrow, c, o);
+            else *reinterpret_cast<f32x4*>(yrow + c) = o;
+        }
+    }
+}
+
 template <int NV>
 static int launch_rownorm_nv(int mode, const float* x, float* y, long M, int L, const float* dw_w, const float* dw_b,
                              const float* is, const float* ih, const float* os, const float* oh, float eps,
                              hipStream_t s, int s32) {
     dim3 grid((unsigned)((M + 3) / 4));
-    if (mode == RN_DWCONV)
-        hipLaunchKernelGGL((rownorm_kernel<NV, RN_DWCONV>), grid, dim3(256), 0, s, x, y, M, L, dw_w, dw_b, is, ih, os, oh, eps, s32);
+    if (mode == RN_DWCONV) {
+        constexpr int R = 4;
+        const int B = (int)(M / L);
+        const long waves = (long)B * ((L + R - 1) / R);
+        hipLaunchKernelGGL((dwconv_ln_kernel<NV, R>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, y, B, L, dw_w, dw_b,
+                           os, oh, eps, s32);
+    }
     else if (mode == RN_PLAIN)
         hipLaunchKernelGGL((rownorm_kernel<NV, RN_PLAIN>), grid, dim3(256), 0, s, x, y, M, L, dw_w, dw_b, is, ih, os, oh, eps, s32);
     else
