@@ -66,7 +66,8 @@ typedef struct wt_plan  wt_plan;
 typedef enum {
     WT_PLAN_ENCODE = 0,          /* audio (B,T)       -> features (B,512,L) + codes (1,B,L)  */
     WT_PLAN_DECODE = 1,          /* features (B,512,L) -> audio (B, L*hop)                     */
-    WT_PLAN_SEANET_DECODER = 2   /* features (B,512,L) -> audio (B,1,L*hop): encodec.decoder   */
+    WT_PLAN_SEANET_DECODER = 2,  /* features (B,512,L) -> audio (B,1,L*hop): encodec.decoder   */
+    WT_PLAN_HEAD = 3             /* backbone output (B,L,dim) -> audio (B, L*hop): model.head   */
 } wt_plan_kind;
 
 enum {
@@ -129,6 +130,10 @@ int wt_codes_to_features(const wt_model* m, const int64_t* codes, int32_t K, int
  *   backbone_out optional [B][L][dim] fp32 (may be NULL). */
 int wt_decode(const wt_plan* p, const float* features, int32_t bandwidth_id, float* wav_out,
               float* backbone_out, void* workspace, void* stream);
+
+/* Replaces: ISTFTHead.forward (decoder/heads.py:42-67) + ISTFT.forward (decoder/spectral_ops.py:33-75) on its own,
+ * reached by callers as model.head(x).  x [B][L][dim] fp32 (the backbone output), wav_out [B][L*hop]. */
+int wt_head(const wt_plan* p, const float* x, float* wav_out, void* workspace, void* stream);
 
 /* Replaces: SEANetDecoder.forward (encoder/modules/seanet.py:236-238), reached by callers as
  * model.feature_extractor.encodec.decoder(features).  wav_out [B][1][L*hop]. */

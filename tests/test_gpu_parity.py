@@ -382,6 +382,20 @@ def test_seanet_decoder():
     assert rel_l2(got.cpu().numpy(), want.numpy()) < WAV_REL_TOL
 
 
+def test_head_alone_matches_decode(gpu_model):
+    """model.head(model.backbone(f)) == model.decode(f) (decoder/pretrained.py:203-206 composes exactly these)."""
+    name, m, sd = gpu_model
+    from wavtokenizer_amd import synth
+    wav = torch.from_numpy(synth.make_clips(2, 12000, seed=31)).cuda()
+    feats, _ = m.encode_infer(wav, bandwidth_id=BW)
+    full = m.decode(feats, bandwidth_id=BW)
+    x = m.backbone(feats, bandwidth_id=BW)
+    assert x.shape == (2, feats.shape[-1], m.arch.dim)
+    alone = m.head(x)
+    assert alone.shape == full.shape
+    assert rel_l2(alone.cpu().numpy(), full.cpu().numpy()) < 2e-6      # the fp32 backbone output re-split vs split in place
+
+
 def test_plan_introspection_and_timing_hook(gpu_model):
     """wt_plan_* accessors the bench and the debug taps rely on."""
     import ctypes

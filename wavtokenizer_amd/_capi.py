@@ -18,12 +18,12 @@ EXPORTS = [
     "wt_plan_create", "wt_plan_destroy", "wt_plan_workspace_bytes", "wt_plan_frames", "wt_plan_num_launches",
     "wt_plan_find_buffer", "wt_plan_buffer_name", "wt_plan_num_steps", "wt_plan_step_name", "wt_plan_set_timing",
     "wt_plan_read_timing", "wt_encode", "wt_codes_to_features", "wt_decode",
-    "wt_seanet_decode", "wt_sconv1d", "wt_linear", "wt_conv1d_s32", "wt_vq_workspace_bytes", "wt_vq_nearest",
+    "wt_seanet_decode", "wt_head", "wt_sconv1d", "wt_linear", "wt_conv1d_s32", "wt_vq_workspace_bytes", "wt_vq_nearest",
     "wt_resampler_create", "wt_resampler_destroy", "wt_resampler_out_length", "wt_convert_audio", "wt_pcm16",
     "wt_linear_overlap_add",
 ]
 
-WT_PLAN_ENCODE, WT_PLAN_DECODE, WT_PLAN_SEANET_DECODER = 0, 1, 2
+WT_PLAN_ENCODE, WT_PLAN_DECODE, WT_PLAN_SEANET_DECODER, WT_PLAN_HEAD = 0, 1, 2, 3
 WT_PLAN_FLAG_KEEP_STAGES = 1
 WT_PLAN_FLAG_FP32_GEMM = 2
 
@@ -75,6 +75,7 @@ def _load() -> ctypes.CDLL:
     lib.wt_codes_to_features.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p, c_void_p]
     lib.wt_decode.argtypes = [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.wt_seanet_decode.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.wt_head.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.wt_sconv1d.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32,
                                c_int32, c_int32, c_int32, c_void_p]
     lib.wt_linear.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p]

@@ -370,8 +370,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float mag = fminf(expf(lm[e]), 100.f);                 // heads.py:55-56
-                        re[e] = mag * cosf(ph[e]);
-                        im[e] = mag * sinf(ph[e]);
+                        float sn, cs;
+                        sincosf(ph[e], &sn, &cs);                                    // one range reduction for both
+                        re[e] = mag * cs;
+                        im[e] = mag * sn;
                     }
                     const int f = (pc >> 6) * 32 + (pc & 31);          // bin slot
                     if (OUT == OUT_S32) {

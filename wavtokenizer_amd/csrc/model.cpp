@@ -944,6 +944,37 @@ static int build_encode(wt_plan* P) {
     return 0;
 }
 
+// ISTFTHead (heads.py:53-66) on the backbone output xo [M][dim] (S32 when s32): Linear + exp/clip/cos/sin fused ->
+// spectrum rows [re | im]; ISTFT (spectral_ops.py:56-73) as four quarter-size real transforms (one batched GEMM), then
+// the butterflies + window + overlap-add + trim + envelope divide in one pass into the caller's audio buffer
+static void plan_head(wt_plan* P, int xo, bool s32) {
+    const wt_model* M = P->model;
+    const wt_arch& ar = M->arch;
+    const int B = P->B, L = (int)P->L, D = ar.dim;
+    const long Mrows = (long)B * L;
+    const int Kb = M->Kb, hop = ar.hop_length;
+    const int spec = P->buf("head.spec", (size_t)Mrows * 2 * Kb);
+    GemmArgs ah = linear_args(M->head_W, M->head_b, Mrows, 2 * Kb, D);
+    P->step({xo, spec}, [=](const RunCtx& c) {
+        GemmArgs a = ah; a.A = P->ptr(c, xo); a.C = P->ptr(c, spec); a.c_rstride = 2 * Kb; a.head_kb = Kb;
+        if (s32) return gemm_s32(P, a, EPI_HEAD, 1, c.stream);                // spectrum pre-split for the ISTFT GEMM
+        return gemm_auto(P, a, PRO_NONE, EPI_HEAD, c.stream);
+    }, 1, "head.out");
+    const int Kq = M->Kq;
+    const int parts = P->buf("head.parts", (size_t)4 * Mrows * Kq);       // Ce, Co, Se, So: [4][M][Kq]
+    P->step({spec, parts}, [=](const RunCtx& c) {
+        GemmArgs a = linear_args(M->istft_W, nullptr, Mrows, Kq, Kq);
+        a.A = P->ptr(c, spec); a.a_rstride = 2 * Kb; a.zA = Kq;              // z picks the spectrum quarter
+        a.zW = (long)Kq * Kq; a.nz = 4;
+        a.C = P->ptr(c, parts); a.c_rstride = Kq; a.zC = (long)Mrows * Kq;
+        if (s32) return gemm_s32(P, a, EPI_BIAS, 0, c.stream);
+        return gemm_auto(P, a, PRO_NONE, EPI_BIAS, c.stream);
+    }, 1, "head.istft");
+    P->step({parts}, [=](const RunCtx& c) {
+        return launch_istft_ola(P->ptr(c, parts), M->win, M->wsq, c.out_f, B, L, ar.n_fft, hop, Kq, c.stream);
+    }, 1, "head.ola");
+}
+
 static int build_decode(wt_plan* P) {
     const wt_model* M = P->model;
     const wt_arch& ar = M->arch;
@@ -1147,30 +1178,23 @@ static int build_decode(wt_plan* P) {
         if (c.aux) WT_HIP_CHECK(hipMemcpyAsync(c.aux, P->ptr(c, xo), (size_t)Mrows * D * sizeof(float), hipMemcpyDeviceToDevice, c.stream));
         return 0;
     });
-    // ISTFTHead (heads.py:53-66): Linear + exp/clip/cos/sin fused -> spectrum rows [re | im]
-    const int Kb = M->Kb, hop = ar.hop_length;
-    const int spec = P->buf("head.spec", (size_t)Mrows * 2 * Kb);
-    GemmArgs ah = linear_args(M->head_W, M->head_b, Mrows, 2 * Kb, D);
-    P->step({xo, spec}, [=](const RunCtx& c) {
-        GemmArgs a = ah; a.A = P->ptr(c, xo); a.C = P->ptr(c, spec); a.c_rstride = 2 * Kb; a.head_kb = Kb;
-        if (s32) return gemm_s32(P, a, EPI_HEAD, 1, c.stream);                // spectrum pre-split for the ISTFT GEMM
-        return gemm_auto(P, a, PRO_NONE, EPI_HEAD, c.stream);
-    }, 1, "head.out");
-    // ISTFT (spectral_ops.py:56-73): four quarter-size real transforms as one batched GEMM, then the
-    // butterflies + window + overlap-add + trim + envelope divide in one pass
-    const int Kq = M->Kq;
-    const int parts = P->buf("head.parts", (size_t)4 * Mrows * Kq);       // Ce, Co, Se, So: [4][M][Kq]
-    P->step({spec, parts}, [=](const RunCtx& c) {
-        GemmArgs a = linear_args(M->istft_W, nullptr, Mrows, Kq, Kq);
-        a.A = P->ptr(c, spec); a.a_rstride = 2 * Kb; a.zA = Kq;              // z picks the spectrum quarter
-        a.zW = (long)Kq * Kq; a.nz = 4;
-        a.C = P->ptr(c, parts); a.c_rstride = Kq; a.zC = (long)Mrows * Kq;
-        if (s32) return gemm_s32(P, a, EPI_BIAS, 0, c.stream);
-        return gemm_auto(P, a, PRO_NONE, EPI_BIAS, c.stream);
-    }, 1, "head.istft");
-    P->step({parts}, [=](const RunCtx& c) {
-        return launch_istft_ola(P->ptr(c, parts), M->win, M->wsq, c.out_f, B, L, ar.n_fft, hop, Kq, c.stream);
-    }, 1, "head.ola");
+    plan_head(P, xo, s32);
+    return 0;
+}
+
+// ISTFTHead alone (decoder/heads.py:42-67 + spectral_ops.py:33-75): x [B][L][dim] fp32 -> audio [B][L*hop]
+static int build_head(wt_plan* P) {
+    const wt_model* M = P->model;
+    const int B = P->B, L = (int)P->L, D = M->arch.dim;
+    const long Mrows = (long)B * L;
+    const bool s32 = plan_s32(P) && (D % 32 == 0) && M->s32.count(M->head_W) && M->s32.count(M->istft_W);
+    const int xo = P->buf("head.in", (size_t)Mrows * D);
+    P->step({xo}, [=](const RunCtx& c) {
+        if (s32) return launch_split_s32(c.in_f, P->ptr(c, xo), Mrows * D, c.stream);
+        WT_HIP_CHECK(hipMemcpyAsync(P->ptr(c, xo), c.in_f, (size_t)Mrows * D * sizeof(float), hipMemcpyDeviceToDevice, c.stream));
+        return 0;
+    });
+    plan_head(P, xo, s32);
     return 0;
 }
 
@@ -1302,6 +1326,9 @@ int wt_plan_create(const wt_model* m, int32_t kind, int32_t B, int64_t len, int3
     } else if (kind == WT_PLAN_SEANET_DECODER) {
         P->L = len; P->T = len * m->hop;
         rc = build_seanet_decoder(P.get());
+    } else if (kind == WT_PLAN_HEAD) {
+        P->L = len; P->T = len * m->hop;
+        rc = build_head(P.get());
     } else {
         set_error("unknown plan kind"); return WT_ERR_INVALID;
     }
@@ -1401,6 +1428,13 @@ int wt_decode(const wt_plan* p, const float* features, int32_t bandwidth_id, flo
         set_error("wt_decode: bandwidth_id out of range"); return WT_ERR_INVALID;
     }
     RunCtx c{static_cast<char*>(workspace), static_cast<hipStream_t>(stream), features, wav_out, nullptr, backbone_out, bandwidth_id};
+    return run_plan(p, c);
+}
+
+int wt_head(const wt_plan* p, const float* x, float* wav_out, void* workspace, void* stream) {
+    if (!p || p->kind != WT_PLAN_HEAD) { set_error("wt_head: wrong plan kind"); return WT_ERR_INVALID; }
+    if (!x || !wav_out || !workspace) { set_error("wt_head: null buffer"); return WT_ERR_INVALID; }
+    RunCtx c{static_cast<char*>(workspace), static_cast<hipStream_t>(stream), x, wav_out, nullptr, nullptr, 0};
     return run_plan(p, c);
 }
 

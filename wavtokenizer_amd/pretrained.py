@@ -114,8 +114,11 @@ class VocosBackbone(_Holder):
 
 
 class ISTFTHead(_Holder):
-    def forward(self, x):
-        raise NotImplementedError("head is fused with the backbone in WavTokenizer.decode; call decode()")
+    """decoder/heads.py:42-67: callable (B, L, dim) -> (B, L*hop)."""
+
+    @torch.inference_mode()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self._root()._run_head(x)
 
 
 def _build_tree(arch: ArchConfig) -> Tuple[EncodecFeatures, VocosBackbone, ISTFTHead]:
@@ -414,6 +417,16 @@ class WavTokenizer(nn.Module):
         bb = torch.empty((B, L, self._arch.dim), dtype=torch.float32, device=dev) if want_backbone else None
         check(lib.wt_decode(plan, _ptr(features), bw, _ptr(wav), _ptr(bb), _ptr(ws), _stream_ptr(dev)), "wt_decode")
         return wav, bb
+
+    def _run_head(self, x: torch.Tensor) -> torch.Tensor:
+        dev = self._ensure_engine()
+        assert x.dim() == 3 and x.shape[2] == self._arch.dim, "expected the backbone output (B, L, dim)"
+        x = self._as_input(x, dev)
+        B, L, _ = x.shape
+        plan, ws = self._engine.plan(_capi.WT_PLAN_HEAD, B, L, self._plan_flags, dev)
+        wav = torch.empty((B, L * self._arch.hop_length), dtype=torch.float32, device=dev)
+        check(lib.wt_head(plan, _ptr(x), _ptr(wav), _ptr(ws), _stream_ptr(dev)), "wt_head")
+        return wav
 
     def _run_seanet_decoder(self, z: torch.Tensor) -> torch.Tensor:
         dev = self._ensure_engine()
