@@ -382,6 +382,21 @@ def test_seanet_decoder():
     assert rel_l2(got.cpu().numpy(), want.numpy()) < WAV_REL_TOL
 
 
+def test_nan_audio_does_not_fault(gpu_model):
+    """NaN samples poison every VQ distance of their frames: the argmax then selects nothing, and the code must still
+    be a valid index (0, like torch.max on an all-NaN row) instead of an out-of-range codebook gather."""
+    name, m, sd = gpu_model
+    from wavtokenizer_amd import synth
+    wav = torch.from_numpy(synth.make_clips(2, 6000, seed=3)).cuda()
+    wav[1, 100:200] = float("nan")
+    feats, codes = m.encode_infer(wav, bandwidth_id=BW)
+    torch.cuda.synchronize()
+    assert int(codes.min()) >= 0 and int(codes.max()) < 4096
+    assert torch.isfinite(feats).all()                       # features are codebook rows
+    clean_f, clean_c = m.encode_infer(wav[:1], bandwidth_id=BW)
+    assert torch.equal(codes[:, :1], clean_c)                # the clean clip is untouched by its neighbour
+
+
 def test_head_alone_matches_decode(gpu_model):
     """model.head(model.backbone(f)) == model.decode(f) (decoder/pretrained.py:203-206 composes exactly these)."""
     name, m, sd = gpu_model

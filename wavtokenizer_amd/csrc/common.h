@@ -118,7 +118,7 @@ int launch_istft_ola(const float* parts /*[4][M][Kq]*/, const float* win, const 
 int launch_softmax(float* S, int rows, int L, int ld, hipStream_t s, float* P_s32 = nullptr);
 int launch_row_sumsq(const float* x, float* out, long rows, int D, hipStream_t s);
 int launch_vq_finalize(const float* pval, const int* pidx, int nparts, const float* embed, int64_t* codes,
-                       float* feat_ncl, int B, int L, int D, hipStream_t s);
+                       float* feat_ncl, int B, int L, int D, int bins, hipStream_t s);
 int launch_codes_to_features(const int64_t* codes, const float* embed, int K, int bins, int B, long L, int D,
                              float* feat_ncl, hipStream_t s);
 struct LstmArgs {
@@ -154,6 +154,7 @@ struct ResblockArgs {
     long x_bstride;       // elements between clips of x (0 = T*C); x may be a trimmed view of a longer buffer
     int elu_out;          // store elu(y) (the only consumer is ELU -> down conv)
     int out_s32;          // resblock16 only: write y in the S32 split-f16 layout (gemm16s.hip) instead of fp32
+    int dbg;              // resblock16 timing experiments only (WT_RB16_DBG)
 };
 bool resblock_fusable(int C);
 int launch_resblock(const ResblockArgs& a, hipStream_t s);      // fp32 MFMA chain (resblock.hip)

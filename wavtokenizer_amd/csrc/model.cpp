@@ -937,7 +937,7 @@ static int build_encode(wt_plan* P) {
     }, 1, "vq.argmin");
     P->step({pv, pi, emb}, [=](const RunCtx& c) {
         if (int rc = launch_vq_finalize(P->ptr(c, pv), reinterpret_cast<int*>(P->ptr(c, pi)), np, M->embed, c.codes,
-                                        c.out_f, B, L, 512, c.stream)) return rc;
+                                        c.out_f, B, L, 512, bins, c.stream)) return rc;
         if (c.aux) return launch_transpose(P->ptr(c, emb), c.aux, B, L, 512, c.stream);
         return 0;
     }, 2);
@@ -1521,7 +1521,7 @@ int wt_vq_nearest(const float* x, const float* embed, int64_t N, int32_t D, int3
     if (int rc = launch_gemm(a, PRO_NONE, EPI_ARGMAX, s)) return rc;
     for (int64_t r0 = 0; r0 < N; r0 += 8192) {      // finalize keeps one chunk of codes in LDS
         const int n = (int)std::min<int64_t>(8192, N - r0);
-        if (int rc = launch_vq_finalize(pv + r0 * np, pi + r0 * np, np, embed, codes_out + r0, nullptr, 1, n, D, s)) return rc;
+        if (int rc = launch_vq_finalize(pv + r0 * np, pi + r0 * np, np, embed, codes_out + r0, nullptr, 1, n, D, bins, s)) return rc;
     }
     return WT_OK;
 }

@@ -613,7 +613,7 @@ int launch_row_sumsq(const float* x, float* out, long rows, int D, hipStream_t s
 __global__ __launch_bounds__(256) void vq_finalize_kernel(const float* __restrict__ pval, const int* __restrict__ pidx,
                                                           int nparts, const float* __restrict__ embed,
                                                           int64_t* __restrict__ codes, float* __restrict__ feat, int L,
-                                                          int D, int cchunk) {
+                                                          int D, int cchunk, int bins) {
     extern __shared__ int s_code[];
     const int b = blockIdx.x;
     for (int t = threadIdx.x; t < L; t += 256) {
@@ -624,6 +624,9 @@ __global__ __launch_bounds__(256) void vq_finalize_kernel(const float* __restric
             const float v = pval[m * nparts + q];
             if (v > best) { best = v; bi = pidx[m * nparts + q]; }
         }
+        // a row of NaN distances (NaN audio in) selects nothing in the GEMM epilogue: index 0 then, like torch.max on
+        // an all-NaN row, instead of an out-of-range gather below
+        if ((unsigned)bi >= (unsigned)bins) bi = 0;
         s_code[t] = bi;
         if (blockIdx.y == 0) codes[m] = (int64_t)bi;
     }
@@ -638,11 +641,11 @@ __global__ __launch_bounds__(256) void vq_finalize_kernel(const float* __restric
 }
 
 int launch_vq_finalize(const float* pval, const int* pidx, int nparts, const float* embed, int64_t* codes,
-                       float* feat_ncl, int B, int L, int D, hipStream_t s) {
+                       float* feat_ncl, int B, int L, int D, int bins, hipStream_t s) {
     const int cchunk = 64;
     dim3 grid(B, feat_ncl ? (D + cchunk - 1) / cchunk : 1);
     hipLaunchKernelGGL(vq_finalize_kernel, grid, dim3(256), (size_t)L * sizeof(int), s, pval, pidx, nparts, embed,
-                       codes, feat_ncl, L, D, cchunk);
+                       codes, feat_ncl, L, D, cchunk, bins);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -13,6 +13,8 @@
 // down conv that follows) per lane.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace wt {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -194,12 +196,14 @@ __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs
 
     const int fl = lane & 31, fh = lane >> 5;        // MFMA lane: (row or column fl, k half fh)
     const int row0 = wave * 32;                      // this wave's frames inside the tile
+    const int dbg = a.dbg;                           // timing experiments only (WT_RB16_DBG): 1 no tile fill, 2 no MFMA, 4 no store
     constexpr float LO_SCALE = 1.f / 2048.f;
 
     for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int b = (int)(tile / tiles_per_clip);
         const int t0 = (int)(tile - (long)b * tiles_per_clip) * ROWS;
         __syncthreads();                             // previous tile fully consumed (and weights landed)
+        if (dbg & 1) { __syncthreads(); } else
         if (FOLD) {
             // first encoder conv from the staged samples: x[f] = b + sum_j w[j] * wav[refl(f + j - 3)]
             if (tid < WAVN) wtile[tid] = pw;
@@ -267,6 +271,7 @@ __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs
         for (int j = 0; j < TN1; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { a1m[j][r] = 0.f; a1c[j][r] = 0.f; }
+        if (!(dbg & 2))
 #pragma unroll
         for (int ks = 0; ks < L::K1 / 16; ++ks) {
             const int tap = (ks * 16) / C, ci = (ks * 16) % C + 8 * fh;
@@ -309,6 +314,7 @@ __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs
         for (int j = 0; j < TN2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { a2m[j][r] = 0.f; a2c[j][r] = 0.f; }
+        if (!(dbg & 2))
 #pragma unroll
         for (int ks = 0; ks < L::K2 / 16; ++ks) {
             f16x8 bh, bl;
@@ -362,7 +368,7 @@ __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs
             for (int it = 0; it < 32 / RPI; ++it) {
                 const int r = it * RPI + lane / LPR, ch = lane % LPR;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(st + r * XR::bytes + ((ch ^ XR::swz(r)) * 16));
-                if (t0 + row0 + r < a.T) *reinterpret_cast<f32x4*>(a.y + (tbase + r) * C + ch * 4) = v;
+                if (t0 + row0 + r < a.T && !(dbg & 4)) *reinterpret_cast<f32x4*>(a.y + (tbase + r) * C + ch * 4) = v;
             }
         }
     }
@@ -382,7 +388,9 @@ static int launch_rb16(const ResblockArgs& a, hipStream_t s) {
     const long tiles = (long)a.B * ((a.T + ROWS - 1) / ROWS);
     const int per_cu = (int)(160 * 1024 / smem) < 4 ? (int)(160 * 1024 / smem) : 4;
     const long grid = tiles < 256L * per_cu ? tiles : 256L * per_cu;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(ROWS * 2), smem, s, a);
+    ResblockArgs b = a;
+    if (const char* e = getenv("WT_RB16_DBG")) b.dbg = atoi(e);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(ROWS * 2), smem, s, b);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }
