@@ -139,7 +139,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
             if (m < p.M) {
                 const int b = m / p.T_out;
                 const int t = m - b * p.T_out;
-                int pos = t * p.stride - p.pad_left + tp * p.dil;
+                const int tap = p.tap_pair ? (tp >> 1) + (tp & 1) * p.stride : tp;
+                int pos = t * p.stride - p.pad_left + tap * p.dil;
                 bool ok;
                 if (p.pad_mode == PAD_REFLECT) {
                     pos = pos < 0 ? -pos : pos;

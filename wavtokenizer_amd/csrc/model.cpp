@@ -71,6 +71,7 @@ struct wt_model {
     // S32 copies (gemm16s.hip: 128-byte groups [32 x f16 hi | 32 x f16 lo], same footprint as fp32) of the weights
     // whose GEMMs take pre-split activations, keyed the same way
     std::map<const float*, void*> s32;
+    std::map<const float*, bool> s32_tap_pair;       // that S32 copy holds its taps in paired order (GemmArgs::tap_pair)
     // encoder
     float *e0_w = nullptr, *e0_b = nullptr;   // [7][32], [32]
     int e0_k = 7, e0_c = 32;
@@ -500,6 +501,24 @@ static int build_splits(wt_model* M) {
     auto conv = [&](const ConvW& c) { return add_split(M, c.w, (long)c.cout * c.k * c.cin); };
     auto conv32 = [&](const ConvW& c) { return (c.cin % 32) ? 0 : add_s32(M, c.w, (long)c.cout * c.k * c.cin); };
     for (const ResStage& st : M->stages) {      // encoder chain on S32 operands (build_encode)
+        if (st.down.cin % 32 == 0 && st.down.k == 2 * st.r && st.down.k <= 32) {
+            // k = 2 * stride: every input frame feeds two output frames (taps j and j + stride).  Packing the taps as
+            // (0, r, 1, r+1, ...) puts those two reads in adjacent K steps
+            const long n = (long)st.down.cout * st.down.k * st.down.cin;
+            std::vector<float> h((size_t)n), pk((size_t)n);
+            WT_HIP_CHECK(hipMemcpy(h.data(), st.down.w, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+            for (int co = 0; co < st.down.cout; ++co)
+                for (int q = 0; q < st.down.k; ++q) {
+                    const int tap = (q >> 1) + (q & 1) * st.r;
+                    std::memcpy(&pk[((size_t)co * st.down.k + q) * st.down.cin], &h[((size_t)co * st.down.k + tap) * st.down.cin],
+                                st.down.cin * sizeof(float));
+                }
+            float* dpk = nullptr;
+            if (int rc = upload(M, pk, &dpk)) return rc;
+            if (int rc = add_s32(M, dpk, n)) return rc;
+            M->s32[st.down.w] = M->s32.at(dpk);
+            M->s32_tap_pair[st.down.w] = true;
+        } else
         if (int rc = conv32(st.down)) return rc;
         if (int rc = conv32(st.c3)) return rc;
         if (int rc = conv32(st.c1)) return rc;
@@ -673,6 +692,7 @@ static int gemm_s32(const wt_plan* P, const GemmArgs& a, int epi, int out, hipSt
     if (it == P->model->s32.end()) { set_error("internal: no S32 copy of this weight"); return WT_ERR_INVALID; }
     GemmArgs b = a;
     b.W_hi = it->second;
+    b.tap_pair = P->model->s32_tap_pair.count(a.W) ? 1 : 0;
     return launch_gemm16s(b, epi, out, s);
 }
 // The decoder's dense chain runs on S32 operands unless stage taps are kept (fp32 taps) or fp32 GEMMs are forced
