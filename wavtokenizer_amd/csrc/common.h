@@ -18,6 +18,19 @@ void set_error(const std::string& msg);
         }                                                                                       \
     } while (0)
 
+// hipFuncSetAttribute (dynamic LDS size) is per device: a process that drives several GPUs must set it on each one
+struct PerDeviceOnce {
+    bool seen[64] = {};
+    bool first() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        d &= 63;
+        if (seen[d]) return false;
+        seen[d] = true;
+        return true;
+    }
+};
+
 // ---------------------------------------------------------------------------------------------
 // The one dense-contraction kernel of the path: C = epilogue(prologue(gather(A)) . W^T)
 //   A  : activations, time-major rows [clip][time][channel]; a row of the im2col matrix for

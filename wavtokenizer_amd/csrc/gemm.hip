@@ -322,14 +322,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 // ---------------------------------------------------------------------------------- host side
 template <int BM, int BN, int WMs, int WNs, int PRO, int EPI>
 static int launch_one(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
+    static PerDeviceOnce attr_once;
     const size_t smem = 2ull * (BM + BN) * LDS_PITCH * sizeof(float) + (size_t)a.taps * BM * sizeof(unsigned);
     constexpr size_t smem_max = 2ull * (BM + BN) * LDS_PITCH * sizeof(float) + 32ull * BM * sizeof(unsigned);
     auto kern = gemm_kernel<BM, BN, WMs, WNs, PRO, EPI>;
-    if (!attr_set) {
+    if (attr_once.first()) {
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max));
-        attr_set = true;
     }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, 1, a.nz);

@@ -323,14 +323,13 @@ int launch_split_f16x2(const float* w, void* hi, void* lo, long n, hipStream_t s
 // ---------------------------------------------------------------------------------- host side
 template <int BM, int BN, int WMs, int WNs, int PRO, int EPI>
 static int launch16_one(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
+    static PerDeviceOnce attr_once;
     const size_t smem = 2ull * (2 * BM + 2 * BN) * PITCH16 * sizeof(_Float16) + (size_t)a.taps * BM * sizeof(unsigned);
     constexpr size_t smem_max = 2ull * (2 * BM + 2 * BN) * PITCH16 * sizeof(_Float16) + 32ull * BM * sizeof(unsigned);
     auto kern = gemm16_kernel<BM, BN, WMs, WNs, PRO, EPI>;
-    if (!attr_set) {
+    if (attr_once.first()) {
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)smem_max));
-        attr_set = true;
     }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, 1, a.nz), dim3(256), smem, s, a);

@@ -509,7 +509,7 @@ int launch_split_s32(const float* x, void* out, long n, hipStream_t s) {
 // ---------------------------------------------------------------------------------- host side
 template <int BM, int BN, int WMs, int WNs, int NSTAGE, int EPI, int OUT>
 static int launch16s_one(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
+    static PerDeviceOnce attr_once;
     constexpr size_t stage_bytes = (size_t)NSTAGE * (BM + BN) * 128;
     size_t smem = stage_bytes + 2ull * a.taps * BM * sizeof(unsigned);
     constexpr size_t smem_cap = 160 * 1024;
@@ -518,10 +518,9 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
     static_assert(stage_bytes + 2 * BM * sizeof(unsigned) <= smem_cap, "LDS budget");
     if (smem > smem_cap) { set_error("gemm16s: too many taps for this tile's LDS budget"); return -1; }
     auto kern = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT>;
-    if (!attr_set) {
+    if (attr_once.first()) {
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)smem_max));
-        attr_set = true;
     }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     const int ntiles = tiles_m * tiles_n;

@@ -317,11 +317,10 @@ int launch_gn_apply(const float* x, const float* gamma, const float* beta, float
         if (groups % g == 0 && (g * cg) % 32 == 0 && g * cg <= 128) { GB = g; break; }
     if (GB && (cg % 4 == 0) && (size_t)L * GB * cg * 4 <= 96 * 1024 && (C % 4 == 0)) {
         const size_t smem = (size_t)L * GB * cg * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static PerDeviceOnce attr_once;
+        if (attr_once.first()) {
             WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gn_tile_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
             WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gn_tile_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-            attr_set = true;
         }
         dim3 grid(groups / GB, B);
         if (swish) hipLaunchKernelGGL(gn_tile_kernel<1>, grid, dim3(256), smem, s, x, gamma, beta, scale, shift, y, L, C, cg, GB, eps, out_s32);

@@ -234,13 +234,12 @@ __global__ __launch_bounds__(ROWS * 2) void resblock_kernel(const ResblockArgs a
 
 template <int C, int ROWS>
 static int launch_rb(const ResblockArgs& a, hipStream_t s) {
-    static bool attr_set = false;
+    static PerDeviceOnce attr_once;
     constexpr size_t smem = (size_t)RbLayout<C, ROWS>::total * sizeof(float);
     auto kern = resblock_kernel<C, ROWS>;
-    if (!attr_set) {
+    if (attr_once.first()) {
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)smem));
-        attr_set = true;
     }
     const long tiles = (long)a.B * ((a.T + ROWS - 1) / ROWS);
     const int per_cu = (int)(160 * 1024 / smem) < 4 ? (int)(160 * 1024 / smem) : 4;

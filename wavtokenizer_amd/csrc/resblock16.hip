@@ -376,14 +376,13 @@ __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs
 
 template <int C, int ROWS, int FOLD>
 static int launch_rb16(const ResblockArgs& a, hipStream_t s) {
-    static bool attr_set = false;
+    static PerDeviceOnce attr_once;
     constexpr size_t smem = (size_t)Rb16Layout<C, ROWS>::total;
     static_assert(smem <= 160 * 1024, "LDS budget");
     auto kern = resblock16_kernel<C, ROWS, FOLD>;
-    if (!attr_set) {
+    if (attr_once.first()) {
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)smem));
-        attr_set = true;
     }
     const long tiles = (long)a.B * ((a.T + ROWS - 1) / ROWS);
     const int per_cu = (int)(160 * 1024 / smem) < 4 ? (int)(160 * 1024 / smem) : 4;
