@@ -102,6 +102,13 @@ def _worker(rank, world, port, n_clips, q):
     m = _FakeCodec()
     f, c = m.encode_infer(wav)
     ok = torch.equal(codes, c) and (rank != 0 or torch.equal(out, m.decode(f))) and (rank == 0 or out is None)
+    # the non-blocking form used by bench.py gives the same result
+    from wavtokenizer_amd.sharding import gather_async, shard_bounds
+    lo, hi = shard_bounds(n_clips, rank, world)
+    counts = [shard_bounds(n_clips, r, world)[1] - shard_bounds(n_clips, r, world)[0] for r in range(world)]
+    fl, cl = m.encode_infer(wav[lo:hi])
+    codes2, out2 = gather_async(cl, m.decode(fl), dist, world, rank, dst=0, counts=counts).result()
+    ok = ok and torch.equal(codes2, c) and (rank != 0 or torch.equal(out2, m.decode(f))) and (rank == 0 or out2 is None)
     q.put((rank, bool(ok), tuple(codes.shape)))
     dist.barrier()
     dist.destroy_process_group()
