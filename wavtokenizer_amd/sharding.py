@@ -59,18 +59,26 @@ class PendingGather:
     """An end-of-step exchange in flight on the collective stream (RCCL runs it beside the next step's kernels).
     `result()` waits for it (stream-wise on GPU backends) and assembles (codes of all clips, waveforms on `dst`)."""
 
-    def __init__(self, works, codes_buf, wav_bufs, counts, world, K, rank, dst):
-        self._works, self._codes_buf, self._wav_bufs = works, codes_buf, wav_bufs
+    def __init__(self, works, codes_buf, wav_big, wav_bufs, counts, world, K, rank, dst):
+        self._works, self._codes_buf, self._wav_big, self._wav_bufs = works, codes_buf, wav_big, wav_bufs
         self._counts, self._world, self._K, self._rank, self._dst = counts, world, K, rank, dst
 
     def result(self):
         for w in self._works:
             w.wait()
-        c = self._codes_buf.view(self._world, self._K, max(self._counts), -1)
-        codes = torch.cat([c[r, :, :self._counts[r]] for r in range(self._world)], dim=1)
+        bmax = max(self._counts)
+        even = min(self._counts) == bmax
+        c = self._codes_buf.view(self._world, self._K, bmax, -1)
+        if even and self._K == 1:
+            codes = c.view(1, self._world * bmax, -1)                # ranks are already in clip order: no copy
+        else:
+            codes = torch.cat([c[r, :, :self._counts[r]] for r in range(self._world)], dim=1)
         wav = None
         if self._rank == self._dst:
-            wav = torch.cat([self._wav_bufs[r][:self._counts[r]] for r in range(self._world)], dim=0)
+            if even:
+                wav = self._wav_big.view(self._world * bmax, -1)     # gathered straight into one buffer: no copy
+            else:
+                wav = torch.cat([self._wav_bufs[r][:self._counts[r]] for r in range(self._world)], dim=0)
         return codes, wav
 
 
@@ -84,9 +92,11 @@ def gather_async(codes_local: torch.Tensor, wav_local: torch.Tensor, dist, world
     bmax = max(counts)
     codes_buf = torch.empty((world * K, bmax, L), dtype=codes_local.dtype, device=codes_local.device)
     w1 = dist.all_gather_into_tensor(codes_buf, _pad_rows(codes_local, 1, bmax), async_op=True)
-    wav_bufs = [torch.empty((bmax, T), dtype=wav_local.dtype, device=wav_local.device) for _ in range(world)] if rank == dst else None
+    # the per-rank receive buffers are slices of ONE tensor, so with even shards the gathered batch needs no concatenation
+    wav_big = torch.empty((world, bmax, T), dtype=wav_local.dtype, device=wav_local.device) if rank == dst else None
+    wav_bufs = list(wav_big.unbind(0)) if rank == dst else None
     w2 = dist.gather(_pad_rows(wav_local, 0, bmax), wav_bufs, dst=dst, async_op=True)
-    return PendingGather([w1, w2], codes_buf, wav_bufs, counts, world, K, rank, dst)
+    return PendingGather([w1, w2], codes_buf, wav_big, wav_bufs, counts, world, K, rank, dst)
 
 
 def roundtrip_sharded(model, wav_all: torch.Tensor, bandwidth_id: torch.Tensor, dist, rank: int, world: int,
