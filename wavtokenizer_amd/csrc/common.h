@@ -153,6 +153,21 @@ struct LstmArgs {
     int f16x3;            // W0 / W1 are the f16 (hi, lo) packings and the state is kept quad-split (ops.hip)
 };
 int launch_lstm_step(const LstmArgs& a, int s, hipStream_t stream);
+// the whole recurrence in one persistent launch (lstm_persist.hip): per-XCD clip groups, weights resident in registers
+struct LstmPersistArgs {
+    const float* xg0;     // [L][B][4H] layer-0 input projection (+ both biases), packed gate order
+    const void* Wp;       // [3 roles][32 wg][4 tiles][16 blk][hi, lo][64 lanes][8 halves]: W_hh_l0, W_ih_l1, W_hh_l1
+    const float* b1;      // [4H] packed b_ih_l1 + b_hh_l1
+    const float* x;       // [B][L][H] skip input
+    float* y;             // [B][L][H] output
+    void* hx;             // lstm_persist_hx_bytes(): per-XCD exchange buffers, zero-filled before the launch
+    unsigned* ctl;        // lstm_persist_ctl_bytes(): tickets / arrival counters / error flag, zero-filled before the launch
+    int B, L, H, Bx;      // Bx = clips per XCD = ceil(B / 8) <= 16
+    int elu_out, out_s32;
+};
+size_t lstm_persist_hx_bytes();
+size_t lstm_persist_ctl_bytes();
+int launch_lstm_persist(const LstmPersistArgs& a, hipStream_t stream);
 struct ResblockArgs {
     const float* x;       // [B][T][C] raw block input (unused when wav is set)
     const float* wav;     // optional [B][T]: fold SEANetEncoder model[0] (k=7, 1 -> 32) into the tile load

@@ -1,0 +1,211 @@
+// SLSTM (encoder/modules/lstm.py:12-39) as ONE persistent launch: the recurrence of all L steps of both layers.
+//
+// The step-per-launch kernel (ops.hip) spends 3.2-3.5 of its 8 us per step in the dependent launch itself.  A
+// persistent kernel needs a barrier between steps instead, and a device-wide one is no cheaper (the eight XCDs' L2s
+// are not coherent: agent-scope release/acquire costs 18 us per round, tools/micro/xcd_barrier.hip).  So the work is
+// cut so that no data ever crosses an XCD:  XCD x owns clips [x*Bx, (x+1)*Bx) — clips are independent — and runs the
+// whole network for them on its 32 CUs; workgroup w of the XCD owns hidden units [16w, 16w+16) of both layers, keeps
+// their recurrent weights resident in registers for the entire sequence (three wave roles x four 16-row gate tiles =
+// 12 waves: W_hh_l0, W_ih_l1, W_hh_l1, as split-f16 hi/lo operands of v_mfma_f32_16x16x32_f16), and the 32
+// workgroups exchange the new hidden state once per step through the XCD's own L2: plain stores (write-through),
+// loads that skip the CU's L1 (sc1), and an arrival counter bumped with an atomic that is performed in that L2.
+// Measured round trip of such a barrier: 2.7 us.
+//
+// Placement: the hardware dispatches workgroup i to XCD i % 8 (measured 256/256, 32 per XCD); the kernel does not
+// rely on the order, it reads HW_REG_XCC_ID and takes a ticket per XCD, and it never spins unboundedly: a round that
+// does not complete (an XCD with fewer than 32 resident workgroups) sets `err` in the control block and every
+// workgroup leaves.
+#include "common.h"
+
+namespace wt {
+
+typedef float f32x4p __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8p __attribute__((ext_vector_type(8)));
+
+static constexpr int PW = 12;                      // waves per workgroup: 3 roles x 4 gate tiles
+static constexpr int HROW = 2 * 2048;              // staged state row: [layer 0 | layer 1], each 512 k in S32 (2048 B)
+static constexpr int HPITCH = HROW + 64;           // LDS row pitch (2-way instead of 16-way bank conflicts)
+static constexpr long SPIN_LIMIT = 1L << 22;
+static constexpr int NLDS = 5;                      // lo-weight blocks kept in LDS instead of registers
+
+__device__ __forceinline__ float sigm_p(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanh_p(float x) {
+    const float ax = fabsf(x);
+    const float e = __expf(-2.f * ax);
+    const float t = ax < 0.04f ? ax * (1.f - ax * ax * (1.f / 3.f)) : (1.f - e) * __builtin_amdgcn_rcpf(1.f + e);
+    return copysignf(t, x);
+}
+
+__global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersistArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char sm_p[];
+    char* hst = sm_p;                                                   // [16 clips][HPITCH]
+    float* gbuf = reinterpret_cast<float*>(sm_p + 16 * HPITCH);         // [3 roles][4 tiles][16 clips][17]
+    // the register file holds 16 hi + 13 lo weight blocks per lane at three waves per SIMD; the last NLDS lo blocks live here
+    f32x4p* wlds = reinterpret_cast<f32x4p*>(sm_p + 16 * HPITCH + 3 * 4 * 16 * 17 * sizeof(float)) + (threadIdx.x >> 6) * NLDS * 64 + (threadIdx.x & 63);
+    __shared__ unsigned s_xcc, s_w, s_stop;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int role = wave >> 2, ntile = wave & 3;
+    const int li = lane & 15, lk = lane >> 4;
+    if (tid == 0) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7;          // HW_REG_XCC_ID[3:0]
+        s_xcc = xcc;
+        s_w = __hip_atomic_fetch_add(a.ctl + xcc * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        s_stop = 0;
+    }
+    __syncthreads();
+    const int xcc = (int)s_xcc, w = (int)s_w;
+    if (w >= 32) return;                                 // more than 32 workgroups on this XCD: the extra ones have no role
+    const int H = 512, B = a.B, L = a.L;
+    const int c0g = xcc * a.Bx;
+    const int nb = B - c0g < a.Bx ? B - c0g : a.Bx;      // clips of this XCD
+    if (nb <= 0) return;                                 // uniform over the XCD's workgroups
+    unsigned* cnt = a.ctl + 256 + xcc * 32;              // this XCD's arrival counter (own cache line)
+    unsigned* err = a.ctl + 512;
+    char* hx = reinterpret_cast<char*>(a.hx) + (size_t)xcc * (2 * 2 * 16 * 2048);    // [parity][layer][clip][2048 B]
+    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(hx, 0, 2 * 2 * 16 * 2048, 0x00020000);
+
+    // ---- resident weights: [role][wg][tile][blk 16][hi, lo][lane][8 halves]
+    f16x8p wh[16], wl[16 - NLDS];
+    {
+        const f32x4p* wp = reinterpret_cast<const f32x4p*>(a.Wp) + ((((size_t)role * 32 + w) * 4 + ntile) * 16 * 2) * 64 + lane;
+#pragma unroll
+        for (int blk = 0; blk < 16; ++blk) {
+            wh[blk] = __builtin_bit_cast(f16x8p, wp[(blk * 2 + 0) * 64]);
+            if (blk < 16 - NLDS) wl[blk] = __builtin_bit_cast(f16x8p, wp[(blk * 2 + 1) * 64]);
+            else wlds[(blk - (16 - NLDS)) * 64] = wp[(blk * 2 + 1) * 64];
+        }
+    }
+    // ---- cell threads: (layer, clip, unit) fixed for the whole sequence, cell state in a register
+    const int c_layer = tid >> 8, c_clip = (tid >> 4) & 15, c_unit = tid & 15;
+    const bool c_thr = tid < 512 && c_clip < nb;
+    const int c_nt = c_unit >> 2, c_u4 = c_unit & 3;
+    const int j = 16 * w + c_unit;                       // hidden unit
+    const long gclip = c0g + c_clip;
+    float cst = 0.f;
+    float bias[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c_thr && c_layer == 1) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias[g] = a.b1[64 * w + 16 * c_nt + g * 4 + c_u4];
+    }
+
+    for (int e = tid; e < 16 * HPITCH / 16; e += 64 * PW) reinterpret_cast<f32x4p*>(hst)[e] = (f32x4p){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    for (int s = 0; s <= L; ++s) {
+        // layer-0 input projection of this step (independent of the recurrence): requested before the wait
+        float xg[4] = {0.f, 0.f, 0.f, 0.f};
+        float xs = 0.f;
+        if (c_thr && c_layer == 0 && s < L) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xg[g] = a.xg0[((long)s * B + gclip) * (4 * H) + 64 * w + 16 * c_nt + g * 4 + c_u4];
+        }
+        if (c_thr && c_layer == 1 && s >= 1) xs = a.x[(gclip * L + (s - 1)) * H + j];
+
+        // 1. everybody on this XCD has published step s-1
+        if (s > 0) {
+            if (tid == 0) {
+                const unsigned want = 32u * (unsigned)s;
+                long spin = 0;
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    if (++spin > SPIN_LIMIT || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s_stop = 1;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            if (s_stop) return;
+        }
+        // 2. stage the state of step s-1 (both layers, this XCD's 16 clip rows) from L2 into LDS, skipping the CU's L1
+        {
+            const int par = (s - 1) & 1;
+            // rows of clips >= nb are zero-filled once (below) and never restaged
+            for (int e = tid; e < 2 * nb * 128; e += 64 * PW) {
+                const int c16 = e & 127, lc = e >> 7, layer = lc / nb, clip = lc - layer * nb;
+                f32x4p v = {0.f, 0.f, 0.f, 0.f};
+                if (s > 0)
+                    v = __builtin_bit_cast(f32x4p, __builtin_amdgcn_raw_buffer_load_b128(
+                            rsH, ((par * 2 + layer) * 16 + clip) * 2048 + c16 * 16, 0, 16 /* sc1: miss the CU's L1, hit the XCD's L2 */));
+                *reinterpret_cast<f32x4p*>(hst + clip * HPITCH + layer * 2048 + c16 * 16) = v;
+            }
+        }
+        __syncthreads();
+        // 3. recurrent products: role 0: W_hh_l0 . h0[s-1] (layer 0, t = s); role 1: W_ih_l1 . h0[s-1]; role 2:
+        //    W_hh_l1 . h1[s-2] (layer 1, t = s-1)
+        {
+            const bool act = role == 0 ? (s < L) : (s >= 1);
+            if (act) {
+                const char* ap = hst + li * HPITCH + (role == 2 ? 2048 : 0) + lk * 16;
+                f32x4p accm = {0.f, 0.f, 0.f, 0.f}, accc = accm;
+#pragma unroll
+                for (int blk = 0; blk < 16; ++blk) {
+                    const f16x8p ah = *reinterpret_cast<const f16x8p*>(ap + blk * 128);
+                    const f16x8p al = *reinterpret_cast<const f16x8p*>(ap + blk * 128 + 64);
+                    const f16x8p wlb = blk < 16 - NLDS ? wl[blk < 16 - NLDS ? blk : 0]
+                                                       : __builtin_bit_cast(f16x8p, wlds[(blk - (16 - NLDS)) * 64]);
+                    accm = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[blk], accm, 0, 0, 0);
+                    accc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wlb, accc, 0, 0, 0);
+                    accc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[blk], accc, 0, 0, 0);
+                }
+                // D: col = lane & 15 (gate row), row = 4 (lane >> 4) + reg (clip)
+                float* gb = gbuf + ((role * 4 + ntile) * 16) * 17;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gb[(4 * lk + r) * 17 + li] = accm[r] + accc[r] * (1.f / 2048.f);
+            }
+        }
+        __syncthreads();
+        // 4. cell update; the new state goes to the exchange buffer of parity s (S32 rows) and, for layer 1, to y
+        if (c_thr && (c_layer == 0 ? (s < L) : (s >= 1))) {
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = g * 4 + c_u4;
+                if (c_layer == 0) pre[g] = gbuf[((0 * 4 + c_nt) * 16 + c_clip) * 17 + col] + xg[g];
+                else pre[g] = (gbuf[((1 * 4 + c_nt) * 16 + c_clip) * 17 + col] + gbuf[((2 * 4 + c_nt) * 16 + c_clip) * 17 + col]) + bias[g];
+            }
+            const float ig = sigm_p(pre[0]), fg = sigm_p(pre[1]), gg = tanh_p(pre[2]), og = sigm_p(pre[3]);
+            cst = fg * cst + ig * gg;
+            const float h = og * tanh_p(cst);
+            _Float16* hrow = reinterpret_cast<_Float16*>(hx + (((s & 1) * 2 + c_layer) * 16 + c_clip) * 2048);
+            const _Float16 hh = (_Float16)h;
+            hrow[(j >> 5) * 64 + (j & 31)] = hh;
+            hrow[(j >> 5) * 64 + 32 + (j & 31)] = (_Float16)((h - (float)hh) * 2048.f);
+            if (c_layer == 1) {
+                const int t = s - 1;
+                const float yv = h + xs;                                // lstm.py:37-38 skip
+                const float o = a.elu_out ? (yv > 0.f ? yv : __expf(yv) - 1.f) : yv;
+                float* yrow = a.y + (gclip * L + t) * H;
+                if (a.out_s32) {
+                    _Float16* yp = reinterpret_cast<_Float16*>(yrow) + ((j >> 5) * 64 + (j & 31));
+                    const _Float16 oh = (_Float16)o;
+                    yp[0] = oh;
+                    yp[32] = (_Float16)((o - (float)oh) * 2048.f);
+                } else {
+                    yrow[j] = o;
+                }
+            }
+        }
+        // 5. publish: the stores are acknowledged by L2 before this workgroup arrives
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0 && s < L) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+size_t lstm_persist_hx_bytes() { return (size_t)8 * 2 * 2 * 16 * 2048; }
+size_t lstm_persist_ctl_bytes() { return 1024 * sizeof(unsigned); }
+
+int launch_lstm_persist(const LstmPersistArgs& a, hipStream_t stream) {
+    if (a.H != 512) { set_error("lstm_persist: built for hidden size 512"); return -1; }
+    if (a.B < 1 || a.Bx < 1 || a.Bx > 16 || 8 * a.Bx < a.B) { set_error("lstm_persist: at most 16 clips per XCD (B <= 128)"); return -1; }
+    static PerDeviceOnce attr_once;
+    const size_t smem = (size_t)16 * HPITCH + (size_t)3 * 4 * 16 * 17 * sizeof(float) + (size_t)PW * NLDS * 1024;
+    if (attr_once.first())
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)smem));
+    hipLaunchKernelGGL(lstm_persist_kernel, dim3(256), dim3(64 * PW), smem, stream, a);
+    WT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace wt

@@ -34,6 +34,7 @@ struct LstmW {
     float* b1 = nullptr;    // [4H]
     float* W0h = nullptr;   // W0 / W1 as f16 (hi, lo) per-lane packings for the split-f16 step kernel (same bytes)
     float* W1h = nullptr;
+    float* Wp = nullptr;    // persistent kernel: [3 roles][32 wg][4 tiles][16 blk][hi, lo][64 lanes][8 halves] (lstm_persist.hip)
 };
 struct ResStage {
     ConvW c3, c1, sc, down;
@@ -208,6 +209,18 @@ static int load_lstm(wt_model* M, TensorMap& tm, const std::string& prefix, int 
         dst[base] = h;
         dst[base + 512] = (_Float16)((v - (float)h) * 2048.f);
     };
+    // persistent-kernel packing (H = 512): packed gate row -> (workgroup = row / 64, tile = row % 64 / 16, li = row % 16);
+    // half p of lane (li, lk) in block blk is W[row][k = 32 blk + 8 lk + p]
+    std::vector<_Float16> Wp(H == 512 ? (size_t)3 * 2048 * 512 * 2 : 0);
+    auto putp = [&](int role, size_t prow, int k, float v) {
+        if (Wp.empty()) return;
+        const size_t wg = prow / 64, tile = (prow % 64) / 16, li = prow % 16;
+        const int blk = k / 32, lk = (k % 32) / 8, pp = k % 8;
+        const size_t base = ((((size_t)role * 32 + wg) * 4 + tile) * 16 + blk) * 2 * 64 * 8 + (size_t)(lk * 16 + li) * 8 + pp;
+        const _Float16 h = (_Float16)v;
+        Wp[base] = h;
+        Wp[base + 64 * 8] = (_Float16)((v - (float)h) * 2048.f);
+    };
     for (int g = 0; g < 4; ++g)
         for (int j = 0; j < H; ++j) {
             const size_t src = (size_t)g * H + j;
@@ -220,6 +233,9 @@ static int load_lstm(wt_model* M, TensorMap& tm, const std::string& prefix, int 
                 put16(W0h, dst, H, k, whh0[src * H + k]);
                 put16(W1h, dst, 2 * H, k, wih1[src * H + k]);
                 put16(W1h, dst, 2 * H, H + k, whh1[src * H + k]);
+                putp(0, dst, k, whh0[src * H + k]);
+                putp(1, dst, k, wih1[src * H + k]);
+                putp(2, dst, k, whh1[src * H + k]);
             }
             b0[dst] = bih0[src] + bhh0[src];
             b1[dst] = bih1[src] + bhh1[src];
@@ -234,6 +250,11 @@ static int load_lstm(wt_model* M, TensorMap& tm, const std::string& prefix, int 
         std::memcpy(t1.data(), W1h.data(), t1.size() * sizeof(float));
         if (int rc = upload(M, t0, &out->W0h)) return rc;
         if (int rc = upload(M, t1, &out->W1h)) return rc;
+        if (!Wp.empty()) {
+            std::vector<float> tp(Wp.size() / 2);
+            std::memcpy(tp.data(), Wp.data(), tp.size() * sizeof(float));
+            if (int rc = upload(M, tp, &out->Wp)) return rc;
+        }
     }
     return upload(M, b1, &out->b1);
 }
@@ -809,6 +830,22 @@ static int plan_lstm(wt_plan* P, const LstmW& w, int B, int L, int H, int xin, c
         if (xin_s32 >= 0) return gemm_s32(P, a, EPI_BIAS, OUT_F32, c.stream);
         return gemm_auto(P, a, PRO_NONE, EPI_BIAS, c.stream);
     });
+    // one persistent launch for the whole recurrence (lstm_persist.hip) when the batch fits its per-XCD clip groups
+    static const bool persist_env = [] { const char* e = getenv("WT_LSTM_PERSIST"); return !e || e[0] != '0'; }();
+    if (persist_env && !(P->flags & WT_PLAN_FLAG_FP32_GEMM) && w.Wp && H == 512 && B <= 128 && L < 65536) {
+        const size_t hxn = lstm_persist_hx_bytes() / sizeof(float), ctn = lstm_persist_ctl_bytes() / sizeof(float);
+        const int hx = P->buf(name + ".hx", hxn + ctn);
+        P->step({xin, xg, hx, y}, [=](const RunCtx& c) {
+            float* hb = P->ptr(c, hx);
+            WT_HIP_CHECK(hipMemsetAsync(hb, 0, (hxn + ctn) * sizeof(float), c.stream));
+            LstmPersistArgs pa;
+            pa.xg0 = P->ptr(c, xg); pa.Wp = w.Wp; pa.b1 = w.b1; pa.x = P->ptr(c, xin); pa.y = P->ptr(c, y);
+            pa.hx = hb; pa.ctl = reinterpret_cast<unsigned*>(hb + hxn);
+            pa.B = B; pa.L = L; pa.H = H; pa.Bx = (B + 7) / 8; pa.elu_out = elu_out ? 1 : 0; pa.out_s32 = y_s32 ? 1 : 0;
+            return launch_lstm_persist(pa, c.stream);
+        }, 2, "lstm.persist");
+        return y;
+    }
     P->step({xin, xg, st, y}, [=](const RunCtx& c) {
         float* s = P->ptr(c, st);
         WT_HIP_CHECK(hipMemsetAsync(s, 0, st_numel * sizeof(float), c.stream));
