@@ -72,6 +72,7 @@ typedef enum {
 
 enum {
     WT_PLAN_FLAG_KEEP_STAGES = 1,  /* never alias stage buffers (debug taps; bigger workspace) */
+    WT_PLAN_FLAG_STEP_LSTM = 4,    /* LSTM as one launch per time step instead of the persistent per-XCD kernel */
     WT_PLAN_FLAG_FP32_GEMM = 2     /* every dense layer on the fp32 MFMA chain; default: the fp32-equivalent
                                       split-f16 kernel (3 f16 MFMAs per product, fp32 accumulate) where covered */
 };

@@ -382,6 +382,23 @@ def test_seanet_decoder():
     assert rel_l2(got.cpu().numpy(), want.numpy()) < WAV_REL_TOL
 
 
+def test_persistent_lstm_matches_step_lstm(gpu_model):
+    """The one-launch LSTM (per-XCD clip groups, XCD-local step barrier) against the launch-per-step kernel: same
+    codes, features equal, waveform to rounding; batch sizes that leave XCDs empty, partly filled and full."""
+    name, m, sd = gpu_model
+    from wavtokenizer_amd import synth
+    for B in (1, 3, 8, 20, 64):
+        wav = torch.from_numpy(synth.make_clips(B, 7200 if B > 8 else 24000, seed=500 + B)).cuda()
+        f1, c1 = m.encode_infer(wav, bandwidth_id=BW)
+        m.set_lstm_mode("step")
+        try:
+            f2, c2 = m.encode_infer(wav, bandwidth_id=BW)
+        finally:
+            m.set_lstm_mode("persistent")
+        assert torch.equal(c1, c2), B
+        assert torch.equal(f1, f2), B
+
+
 def test_nan_audio_does_not_fault(gpu_model):
     """NaN samples poison every VQ distance of their frames: the argmax then selects nothing, and the code must still
     be a valid index (0, like torch.max on an all-NaN row) instead of an out-of-range codebook gather."""

@@ -26,6 +26,7 @@ EXPORTS = [
 WT_PLAN_ENCODE, WT_PLAN_DECODE, WT_PLAN_SEANET_DECODER, WT_PLAN_HEAD = 0, 1, 2, 3
 WT_PLAN_FLAG_KEEP_STAGES = 1
 WT_PLAN_FLAG_FP32_GEMM = 2
+WT_PLAN_FLAG_STEP_LSTM = 4
 
 
 class WtArch(ctypes.Structure):

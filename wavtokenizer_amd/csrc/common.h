@@ -162,6 +162,7 @@ struct LstmPersistArgs {
     float* y;             // [B][L][H] output
     void* hx;             // lstm_persist_hx_bytes(): per-XCD exchange buffers, zero-filled before the launch
     unsigned* ctl;        // lstm_persist_ctl_bytes(): tickets / arrival counters / error flag, zero-filled before the launch
+    unsigned* host_err;   // optional host-mapped word, set to 1 when a step barrier times out
     int B, L, H, Bx;      // Bx = clips per XCD = ceil(B / 8) <= 16
     int elu_out, out_s32;
 };

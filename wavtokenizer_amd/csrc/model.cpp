@@ -631,6 +631,11 @@ struct wt_plan {
     mutable std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending, ev_free;
     mutable double timing_ms = 0.0;
     mutable long timing_n = 0;
+    // persistent LSTM (lstm_persist.hip): a host-mapped word the kernel sets if a step barrier times out (lost
+    // co-residency); checked at the next call, which then reports the failure and falls back to one launch per step
+    unsigned* persist_err_host = nullptr;
+    unsigned* persist_err_dev = nullptr;
+    mutable bool persist_ok = true;
 
     int buf(const std::string& name, size_t numel) {
         wt::BufSpec b;
@@ -830,23 +835,38 @@ static int plan_lstm(wt_plan* P, const LstmW& w, int B, int L, int H, int xin, c
         if (xin_s32 >= 0) return gemm_s32(P, a, EPI_BIAS, OUT_F32, c.stream);
         return gemm_auto(P, a, PRO_NONE, EPI_BIAS, c.stream);
     });
-    // one persistent launch for the whole recurrence (lstm_persist.hip) when the batch fits its per-XCD clip groups
+    // one persistent launch for the whole recurrence (lstm_persist.hip) when the batch fits its per-XCD clip groups and
+    // the device is a full MI355X (256 CUs: one resident workgroup per CU, 32 per XCD)
     static const bool persist_env = [] { const char* e = getenv("WT_LSTM_PERSIST"); return !e || e[0] != '0'; }();
-    if (persist_env && !(P->flags & WT_PLAN_FLAG_FP32_GEMM) && w.Wp && H == 512 && B <= 128 && L < 65536) {
-        const size_t hxn = lstm_persist_hx_bytes() / sizeof(float), ctn = lstm_persist_ctl_bytes() / sizeof(float);
-        const int hx = P->buf(name + ".hx", hxn + ctn);
-        P->step({xin, xg, hx, y}, [=](const RunCtx& c) {
+    bool persist = persist_env && !(P->flags & (WT_PLAN_FLAG_FP32_GEMM | WT_PLAN_FLAG_STEP_LSTM)) && w.Wp && H == 512 && B <= 128 && L < 65536;
+    if (persist) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, P->model->device) != hipSuccess || cus != 256) persist = false;
+    }
+    if (persist && !P->persist_err_host) {
+        void* hp = nullptr;
+        void* dp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+            P->persist_err_host = static_cast<unsigned*>(hp);
+            P->persist_err_dev = static_cast<unsigned*>(dp);
+            *P->persist_err_host = 0;
+        } else {
+            if (hp) (void)hipHostFree(hp);
+            persist = false;
+        }
+    }
+    const size_t hxn = lstm_persist_hx_bytes() / sizeof(float), ctn = lstm_persist_ctl_bytes() / sizeof(float);
+    const int hx = persist ? P->buf(name + ".hx", hxn + ctn) : -1;
+    P->step({xin, xg, st, hx, y}, [=](const RunCtx& c) {
+        if (persist && P->persist_ok) {
             float* hb = P->ptr(c, hx);
             WT_HIP_CHECK(hipMemsetAsync(hb, 0, (hxn + ctn) * sizeof(float), c.stream));
             LstmPersistArgs pa;
             pa.xg0 = P->ptr(c, xg); pa.Wp = w.Wp; pa.b1 = w.b1; pa.x = P->ptr(c, xin); pa.y = P->ptr(c, y);
-            pa.hx = hb; pa.ctl = reinterpret_cast<unsigned*>(hb + hxn);
+            pa.hx = hb; pa.ctl = reinterpret_cast<unsigned*>(hb + hxn); pa.host_err = P->persist_err_dev;
             pa.B = B; pa.L = L; pa.H = H; pa.Bx = (B + 7) / 8; pa.elu_out = elu_out ? 1 : 0; pa.out_s32 = y_s32 ? 1 : 0;
             return launch_lstm_persist(pa, c.stream);
-        }, 2, "lstm.persist");
-        return y;
-    }
-    P->step({xin, xg, st, y}, [=](const RunCtx& c) {
+        }
         float* s = P->ptr(c, st);
         WT_HIP_CHECK(hipMemsetAsync(s, 0, st_numel * sizeof(float), c.stream));
         LstmArgs la;
@@ -1396,6 +1416,7 @@ int wt_plan_create(const wt_model* m, int32_t kind, int32_t B, int64_t len, int3
 }
 void wt_plan_destroy(wt_plan* p) {
     if (!p) return;
+    if (p->persist_err_host) (void)hipHostFree(p->persist_err_host);
     for (auto& ev : p->ev_pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : p->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete p;
@@ -1423,6 +1444,13 @@ int wt_plan_buffer_name(const wt_plan* p, int32_t index, const char** name) {
 
 static int run_plan(const wt_plan* p, const RunCtx& c) {
     WT_HIP_CHECK(hipSetDevice(p->model->device));
+    if (p->persist_err_host && *p->persist_err_host && p->persist_ok) {
+        p->persist_ok = false;            // this and every later call run the LSTM one launch per step
+        *p->persist_err_host = 0;
+        set_error("the previous persistent LSTM launch on this plan lost co-residency (a step barrier timed out) and its "
+                  "outputs are invalid; the plan now runs the LSTM one launch per step");
+        return WT_ERR_HIP;
+    }
     const bool timing = !p->timing_filter.empty();
     for (size_t i = 0; i < p->steps.size(); ++i) {
         const bool timed = timing && p->step_names[i].find(p->timing_filter) != std::string::npos;

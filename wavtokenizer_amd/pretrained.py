@@ -354,6 +354,14 @@ class WavTokenizer(nn.Module):
         self._plan_flags = (self._plan_flags | _capi.WT_PLAN_FLAG_FP32_GEMM) if mode == "f32" else \
             (self._plan_flags & ~_capi.WT_PLAN_FLAG_FP32_GEMM)
 
+    def set_lstm_mode(self, mode: str):
+        """"persistent" (default): the whole LSTM recurrence in one launch (per-XCD clip groups, weights resident);
+        "step": one launch per time step."""
+        if mode not in ("persistent", "step"):
+            raise ValueError("mode must be 'persistent' or 'step'")
+        self._plan_flags = (self._plan_flags | _capi.WT_PLAN_FLAG_STEP_LSTM) if mode == "step" else \
+            (self._plan_flags & ~_capi.WT_PLAN_FLAG_STEP_LSTM)
+
     @property
     def arch(self) -> ArchConfig:
         return self._arch
