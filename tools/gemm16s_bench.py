@@ -110,7 +110,7 @@ def main():
             os.environ["WT_GEMM16S_NONPERSISTENT"] = "1"
             linear(f"{name} s32 128x192x3 non-persistent", M, N, K, 2, 2)
             os.environ.pop("WT_GEMM16S_NONPERSISTENT")
-            for dbg, dn in ((1, "no DMA"), (2, "no MFMA"), (4, "no epilogue"), (5, "no DMA, no epilogue"), (6, "DMA only")):
+            for dbg, dn in ((64, "setprio younger half"), (1, "no DMA"), (2, "no MFMA"), (4, "no epilogue"), (5, "no DMA, no epilogue"), (6, "DMA only")):
                 os.environ["WT_GEMM16S_DBG"] = str(dbg)
                 linear(f"{name} s32 128x192x3 {dn}", M, N, K, 2, 2)
                 os.environ.pop("WT_GEMM16S_DBG")

@@ -269,6 +269,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
     // the epilogue's own loads and stores simply queue behind them.  Past the last tile the DMAs are issued all the
     // same with out-of-range offsets (constant wait counts).
     const int nk = p.K / SBK;
+    if ((p.dbg & 64) && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);     // experiment: static priority for the younger half
     build_table(blockIdx.x, 0);
     __syncthreads();
     loader_set_tile(blockIdx.x, 0);
