@@ -190,6 +190,27 @@ def test_full_batch_against_oracle_and_invariants(gpu_model):
     assert flips <= 4
 
 
+def test_random_ragged_lengths_against_oracle(gpu_model):
+    """Seeded random clip lengths (not multiples of the hop, odd batch sizes): GPU vs the oracle on this host."""
+    from wavtokenizer_amd import synth
+    name, m, sd = gpu_model
+    orc = _oracle(name, sd)
+    rng = np.random.default_rng(20240 + len(name))
+    cases = [(int(rng.integers(1, 6)), int(rng.integers(700, 30000))) for _ in range(5)] + [(3, 2), (2, 7), (1, 1201)]
+    for B, T in cases:
+        wav_np = synth.make_clips(B, T, seed=9000 + T)
+        feats, codes = m.encode_infer(torch.from_numpy(wav_np).cuda(), bandwidth_id=BW)
+        taps = {}
+        with torch.inference_mode():
+            fo, co = orc.encode_infer(torch.from_numpy(wav_np), BW, taps)
+            wo = orc.decode(fo, BW)
+        assert tuple(codes.shape) == tuple(co.shape), (B, T)
+        check_codes(codes.cpu().numpy(), co.numpy(), taps["vq.margin"].numpy(), f"{name} B={B} T={T}")
+        wg = m.decode(fo.cuda(), bandwidth_id=BW)
+        assert tuple(wg.shape) == tuple(wo.shape), (B, T)
+        assert rel_l2(wg.cpu().numpy(), wo.numpy()) < WAV_REL_TOL, (B, T)
+
+
 def test_b8_fixture_codes(gpu_model):
     from wavtokenizer_amd import synth
     from tests.util import NEAR_TIE_MARGIN
