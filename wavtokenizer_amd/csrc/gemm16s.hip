@@ -392,7 +392,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
         // per instruction.  Each 32x32 sub-tile goes through a 4 KB wave-private LDS scratch instead (chunk-swizzled,
         // conflict-free both ways) and is read back with 8 lanes per 128-byte row: every store is then a full line
         // (measured: pwconv1 + GELU 114 -> 109 us; the residual epilogues gained nothing and stay direct).
-        constexpr bool CAN_STAGE = (OUT == OUT_F32 && EPI == EPI_BIAS) ||
+        constexpr bool DUAL = OUT == OUT_S32_DUAL_ELU || OUT == OUT_F32_AND_S32;
+        constexpr bool CAN_STAGE = ((OUT == OUT_F32 || DUAL) && EPI == EPI_BIAS) ||
                                    (OUT == OUT_S32 && (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ELU));
         if (CAN_STAGE && p.stage_epi) {
             char* sc = smem_s + p.stage_off + wave * 4096;
@@ -403,38 +404,44 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
                 for (int j = 0; j < TN; ++j) {
                     const int n0 = n_w + j * 32;
                     if (n0 >= p.N) continue;                       // wave-uniform
+                    // a dual-output launch sends the block through the scratch twice, once per destination format
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int n = n0 + 8 * g + col_h;
-                        f32x4 v = acc4(i, j, g);
-                        if (p.bias && n < p.N) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                        if (EPI == EPI_BIAS_ELU) {
-                            v.x = elu_s(v.x); v.y = elu_s(v.y); v.z = elu_s(v.z); v.w = elu_s(v.w);
-                        } else if (EPI == EPI_BIAS_GELU) {
-                            v.x = gelu_erf_s(v.x); v.y = gelu_erf_s(v.y); v.z = gelu_erf_s(v.z); v.w = gelu_erf_s(v.w);
-                        }
-                        if (OUT == OUT_F32) {
-                            const int ch = 2 * g + (col_h >> 2);
-                            *reinterpret_cast<f32x4*>(sc + row_l * 128 + ((ch ^ sw_w) * 16)) = v;
-                        } else {
-                            f16x4 hi, lo;
-                            hi.x = (_Float16)v.x; hi.y = (_Float16)v.y; hi.z = (_Float16)v.z; hi.w = (_Float16)v.w;
-                            lo.x = (_Float16)((v.x - (float)hi.x) * 2048.f); lo.y = (_Float16)((v.y - (float)hi.y) * 2048.f);
-                            lo.z = (_Float16)((v.z - (float)hi.z) * 2048.f); lo.w = (_Float16)((v.w - (float)hi.w) * 2048.f);
-                            *reinterpret_cast<f16x4*>(sc + row_l * 128 + ((g ^ sw_w) * 16) + 2 * col_h) = hi;
-                            *reinterpret_cast<f16x4*>(sc + row_l * 128 + (((4 + g) ^ sw_w) * 16) + 2 * col_h) = lo;
-                        }
-                    }
-                    // a wave's LDS operations execute in order and the scratch is private to the wave: no barrier
+                    for (int pz = 0; pz < (DUAL ? 2 : 1); ++pz) {
+                        const bool as_f32 = OUT == OUT_F32 || (OUT == OUT_F32_AND_S32 && pz == 0);
 #pragma unroll
-                    for (int it = 0; it < 4; ++it) {
-                        const int r = 8 * it + (lane >> 3), ch = lane & 7;
-                        f32x4 q = *reinterpret_cast<const f32x4*>(sc + r * 128 + ((ch ^ ((r >> 1) & 7)) * 16));
-                        const int m = m_w + i * 32 + r;
-                        const int n = n0 + 4 * ch;                 // fp32 columns; S32: byte ch * 16 of the group at n0
-                        if (m < p.M && (OUT == OUT_S32 || n < p.N)) {
-                            float* dst = Cg + (long)m * p.c_rstride + n;
-                            *reinterpret_cast<f32x4*>(dst) = q;
+                        for (int g = 0; g < 4; ++g) {
+                            const int n = n0 + 8 * g + col_h;
+                            f32x4 v = acc4(i, j, g);
+                            if (p.bias && n < p.N) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                            if (EPI == EPI_BIAS_ELU || (OUT == OUT_S32_DUAL_ELU && pz == 1)) {
+                                v.x = elu_s(v.x); v.y = elu_s(v.y); v.z = elu_s(v.z); v.w = elu_s(v.w);
+                            } else if (EPI == EPI_BIAS_GELU) {
+                                v.x = gelu_erf_s(v.x); v.y = gelu_erf_s(v.y); v.z = gelu_erf_s(v.z); v.w = gelu_erf_s(v.w);
+                            }
+                            if (as_f32) {
+                                const int ch = 2 * g + (col_h >> 2);
+                                *reinterpret_cast<f32x4*>(sc + row_l * 128 + ((ch ^ sw_w) * 16)) = v;
+                            } else {
+                                f16x4 hi, lo;
+                                hi.x = (_Float16)v.x; hi.y = (_Float16)v.y; hi.z = (_Float16)v.z; hi.w = (_Float16)v.w;
+                                lo.x = (_Float16)((v.x - (float)hi.x) * 2048.f); lo.y = (_Float16)((v.y - (float)hi.y) * 2048.f);
+                                lo.z = (_Float16)((v.z - (float)hi.z) * 2048.f); lo.w = (_Float16)((v.w - (float)hi.w) * 2048.f);
+                                *reinterpret_cast<f16x4*>(sc + row_l * 128 + ((g ^ sw_w) * 16) + 2 * col_h) = hi;
+                                *reinterpret_cast<f16x4*>(sc + row_l * 128 + (((4 + g) ^ sw_w) * 16) + 2 * col_h) = lo;
+                            }
+                        }
+                        // a wave's LDS operations execute in order and the scratch is private to the wave: no barrier
+                        float* dbase = pz == 0 ? Cg : p.C2 + (long)z * p.zC;
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) {
+                            const int r = 8 * it + (lane >> 3), ch = lane & 7;
+                            f32x4 q = *reinterpret_cast<const f32x4*>(sc + r * 128 + ((ch ^ ((r >> 1) & 7)) * 16));
+                            const int m = m_w + i * 32 + r;
+                            const int n = n0 + 4 * ch;             // fp32 columns; S32: byte ch * 16 of the group at n0
+                            if (m < p.M && (!as_f32 || n < p.N)) {
+                                float* dst = dbase + (long)m * p.c_rstride + n;
+                                *reinterpret_cast<f32x4*>(dst) = q;
+                            }
                         }
                     }
                 }
@@ -534,11 +541,13 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
     if (G < 8 || ntiles <= G || a.K / SBK < NSTAGE + 1 || (np && np[0] == '1')) G = ntiles;
     GemmArgs b = a;
     {   // staged epilogue: 4 KB of scratch per wave after the stages and tables, when it fits and the layout allows
-        constexpr bool can_stage = (OUT == OUT_F32 && EPI == EPI_BIAS) ||
+        constexpr bool can_stage = ((OUT == OUT_F32 || OUT == OUT_S32_DUAL_ELU || OUT == OUT_F32_AND_S32) && EPI == EPI_BIAS) ||
                                    (OUT == OUT_S32 && (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ELU));
         const size_t off = (smem + 127) / 128 * 128;
         const char* ns = getenv("WT_GEMM16S_NOSTAGE");
-        if (can_stage && off + (size_t)WMs * WNs * 4096 <= smem_cap && a.N % 32 == 0 && !(ns && ns[0] == '1')) {
+        constexpr bool dual = OUT == OUT_S32_DUAL_ELU || OUT == OUT_F32_AND_S32;
+        if (can_stage && off + (size_t)WMs * WNs * 4096 <= smem_cap && a.N % 32 == 0 && !(ns && ns[0] == '1') &&
+            !(dual && ns && ns[0] == '2')) {
             b.stage_epi = 1; b.stage_off = (int)off;
             smem = off + (size_t)WMs * WNs * 4096;
         }
