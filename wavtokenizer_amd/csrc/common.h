@@ -160,11 +160,12 @@ struct LstmPersistArgs {
     const float* b1;      // [4H] packed b_ih_l1 + b_hh_l1
     const float* x;       // [B][L][H] skip input
     float* y;             // [B][L][H] output
-    void* hx;             // lstm_persist_hx_bytes(): per-XCD exchange buffers, zero-filled before the launch
-    unsigned* ctl;        // lstm_persist_ctl_bytes(): tickets / arrival counters / error flag, zero-filled before the launch
+    void* hx;             // lstm_persist_hx_bytes(): per-XCD exchange buffers  } filled before the launch with 0xFF bytes
+    unsigned* ctl;        // lstm_persist_ctl_bytes(): tickets / counters / error } (data_flag) or zeros (counter form)
     unsigned* host_err;   // optional host-mapped word, set to 1 when a step barrier times out
     int B, L, H, Bx;      // Bx = clips per XCD = ceil(B / 8) <= 16
     int elu_out, out_s32;
+    int data_flag;        // 1: the exchanged state carries its own readiness marks (default); 0: arrival counter per step
 };
 size_t lstm_persist_hx_bytes();
 size_t lstm_persist_ctl_bytes();

@@ -26,7 +26,8 @@ static constexpr int PW = 12;                      // waves per workgroup: 3 rol
 static constexpr int HROW = 2 * 2048;              // staged state row: [layer 0 | layer 1], each 512 k in S32 (2048 B)
 static constexpr int HPITCH = HROW + 64;           // LDS row pitch (2-way instead of 16-way bank conflicts)
 static constexpr long SPIN_LIMIT = 1L << 22;
-static constexpr int NLDS = 5;                      // lo-weight blocks kept in LDS instead of registers
+static constexpr long SPIN_LIMIT_DF = 1L << 20;    // polls of the state itself (about a microsecond each)
+static constexpr int NLDS = 6;                      // lo-weight blocks kept in LDS instead of registers
 
 __device__ __forceinline__ float sigm_p(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float tanh_p(float x) {
@@ -36,7 +37,24 @@ __device__ __forceinline__ float tanh_p(float x) {
     return copysignf(t, x);
 }
 
+// a 32-bit word holds two f16 halves; nonzero iff one of them is the "not written yet" mark 0xFFFF
+__device__ __forceinline__ unsigned has_mark(unsigned d) { return (~d - 0x00010001u) & d & 0x80008000u; }
+// a state half that would collide with the mark (a NaN with an all-ones payload) is stored as the canonical NaN
+__device__ __forceinline__ _Float16 no_mark(_Float16 v) {
+    const unsigned short b = __builtin_bit_cast(unsigned short, v);
+    return __builtin_bit_cast(_Float16, (unsigned short)(b == 0xFFFFu ? 0x7E00u : b));
+}
+
+// DF (default): the state exchange carries its own readiness.  Three buffers per XCD; every (layer, clip, unit) half is
+// either the mark 0xFFFF or data: the step-s reader polls the DATA of step s-1 (buffer (s-1) % 3) until no mark is left,
+// a writer stores step s into buffer s % 3 and, one step ahead of need, re-marks its own slice of buffer (s+1) % 3 (last
+// read during step s-1, which every workgroup has finished once this one holds all of step s-1; the re-mark is acknowledged
+// by L2 before the step's data is stored, so whoever sees that data can never see the older contents again).  Per step
+// that is ONE L2 round trip on each side (store; load) instead of store -> acknowledge -> counter atomic -> poll -> load.
+// !DF: the arrival-counter form (two buffers), kept for comparison (WT_LSTM_PERSIST=2).
+template <bool DF>
 __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersistArgs a) {
+    constexpr int NBUF = DF ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) char sm_p[];
     char* hst = sm_p;                                                   // [16 clips][HPITCH]
     float* gbuf = reinterpret_cast<float*>(sm_p + 16 * HPITCH);         // [3 roles][4 tiles][16 clips][17]
@@ -49,7 +67,8 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
     if (tid == 0) {
         const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7;          // HW_REG_XCC_ID[3:0]
         s_xcc = xcc;
-        s_w = __hip_atomic_fetch_add(a.ctl + xcc * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // DF: the control block starts as all-ones like the state buffers (one memset), so the first ticket is ~0u + 1
+        s_w = __hip_atomic_fetch_add(a.ctl + xcc * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + (DF ? 1u : 0u);
         s_stop = 0;
     }
     __syncthreads();
@@ -61,8 +80,8 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
     if (nb <= 0) return;                                 // uniform over the XCD's workgroups
     unsigned* cnt = a.ctl + 256 + xcc * 32;              // this XCD's arrival counter (own cache line)
     unsigned* err = a.ctl + 512;
-    char* hx = reinterpret_cast<char*>(a.hx) + (size_t)xcc * (2 * 2 * 16 * 2048);    // [parity][layer][clip][2048 B]
-    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(hx, 0, 2 * 2 * 16 * 2048, 0x00020000);
+    char* hx = reinterpret_cast<char*>(a.hx) + (size_t)xcc * (NBUF * 2 * 16 * 2048);    // [buffer][layer][clip][2048 B]
+    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(hx, 0, NBUF * 2 * 16 * 2048, 0x00020000);
 
     // ---- resident weights: [role][wg][tile][blk 16][hi, lo][lane][8 halves]
     f16x8p wh[16], wl[16 - NLDS];
@@ -82,11 +101,6 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
     const int j = 16 * w + c_unit;                       // hidden unit
     const long gclip = c0g + c_clip;
     float cst = 0.f;
-    float bias[4] = {0.f, 0.f, 0.f, 0.f};
-    if (c_thr && c_layer == 1) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bias[g] = a.b1[64 * w + 16 * c_nt + g * 4 + c_u4];
-    }
 
     for (int e = tid; e < 16 * HPITCH / 16; e += 64 * PW) reinterpret_cast<f32x4p*>(hst)[e] = (f32x4p){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
@@ -98,8 +112,76 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
 #pragma unroll
             for (int g = 0; g < 4; ++g) xg[g] = a.xg0[((long)s * B + gclip) * (4 * H) + 64 * w + 16 * c_nt + g * 4 + c_u4];
         }
-        if (c_thr && c_layer == 1 && s >= 1) xs = a.x[(gclip * L + (s - 1)) * H + j];
+        if (c_thr && c_layer == 1 && s >= 1) {
+            xs = a.x[(gclip * L + (s - 1)) * H + j];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xg[g] = a.b1[64 * w + 16 * c_nt + g * 4 + c_u4];     // layer 1: its bias (an L1 hit; no registers held across steps)
+        }
 
+        if (DF) {
+            // 1+2. poll the state of step s-1 itself (L2 loads that skip the CU's L1) until every half is data, then
+            //      stage it in LDS; h0[-1] = h1[-1] = 0 are not loaded (layer 1 runs one step behind: its first
+            //      state appears in buffer 1)
+            const int rb = (s + 2) % 3, tot = 2 * nb * 128;
+            // up to 16 clips: 4096 chunks = 6 per thread, polled three at a time (the weights leave 12 free registers)
+            for (int e0 = tid; e0 < tot; e0 += 3 * 64 * PW) {
+                f32x4p v[3];
+                unsigned need = 0;
+#pragma unroll
+                for (int it = 0; it < 3; ++it) {
+                    const int e = e0 + it * 64 * PW;
+                    if (e < tot && s >= 1 + (e >> 7) / nb) need |= 1u << it;
+                }
+                unsigned pend = need;
+                long spin = 0;
+                while (pend) {
+#pragma unroll
+                    for (int it = 0; it < 3; ++it)
+                        if (pend >> it & 1) {
+                            const int e = e0 + it * 64 * PW;
+                            const int c16 = e & 127, lc = e >> 7, layer = lc / nb, clip = lc - layer * nb;
+                            v[it] = __builtin_bit_cast(f32x4p, __builtin_amdgcn_raw_buffer_load_b128(
+                                        rsH, ((rb * 2 + layer) * 16 + clip) * 2048 + c16 * 16, 0, 16 /* sc1 */));
+                        }
+                    unsigned still = 0;
+#pragma unroll
+                    for (int it = 0; it < 3; ++it)
+                        if (pend >> it & 1) {
+                            const unsigned m = has_mark(__builtin_bit_cast(unsigned, v[it].x)) | has_mark(__builtin_bit_cast(unsigned, v[it].y)) |
+                                               has_mark(__builtin_bit_cast(unsigned, v[it].z)) | has_mark(__builtin_bit_cast(unsigned, v[it].w));
+                            if (m) still |= 1u << it;
+                        }
+                    pend = still;
+                    if (pend) {
+                        if (++spin > SPIN_LIMIT_DF || ((spin & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u)) {
+                            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (a.host_err) __hip_atomic_store(a.host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            s_stop = 1;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < 3; ++it) {
+                    const int e = e0 + it * 64 * PW;
+                    if (e < tot) {
+                        const int c16 = e & 127, lc = e >> 7, layer = lc / nb, clip = lc - layer * nb;
+                        *reinterpret_cast<f32x4p*>(hst + clip * HPITCH + layer * 2048 + c16 * 16) =
+                            (need >> it & 1) ? v[it] : (f32x4p){0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+            }
+            __syncthreads();
+            if (s_stop) return;
+            // this workgroup now holds all of step s-1, so every workgroup is past its reads of step s-2: re-mark the
+            // own slice of the buffer that held it (it is written again at step s+1)
+            if (c_thr) {
+                unsigned short* mrow = reinterpret_cast<unsigned short*>(hx + ((((s + 1) % 3) * 2 + c_layer) * 16 + c_clip) * 2048);
+                mrow[(j >> 5) * 64 + (j & 31)] = 0xFFFFu;
+                mrow[(j >> 5) * 64 + 32 + (j & 31)] = 0xFFFFu;
+            }
+        } else {
         // 1. everybody on this XCD has published step s-1
         if (s > 0) {
             if (tid == 0) {
@@ -131,6 +213,7 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
             }
         }
         __syncthreads();
+        }
         // 3. recurrent products: role 0: W_hh_l0 . h0[s-1] (layer 0, t = s); role 1: W_ih_l1 . h0[s-1]; role 2:
         //    W_hh_l1 . h1[s-2] (layer 1, t = s-1)
         {
@@ -162,15 +245,17 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
             for (int g = 0; g < 4; ++g) {
                 const int col = g * 4 + c_u4;
                 if (c_layer == 0) pre[g] = gbuf[((0 * 4 + c_nt) * 16 + c_clip) * 17 + col] + xg[g];
-                else pre[g] = (gbuf[((1 * 4 + c_nt) * 16 + c_clip) * 17 + col] + gbuf[((2 * 4 + c_nt) * 16 + c_clip) * 17 + col]) + bias[g];
+                else pre[g] = (gbuf[((1 * 4 + c_nt) * 16 + c_clip) * 17 + col] + gbuf[((2 * 4 + c_nt) * 16 + c_clip) * 17 + col]) + xg[g];
             }
             const float ig = sigm_p(pre[0]), fg = sigm_p(pre[1]), gg = tanh_p(pre[2]), og = sigm_p(pre[3]);
             cst = fg * cst + ig * gg;
             const float h = og * tanh_p(cst);
-            _Float16* hrow = reinterpret_cast<_Float16*>(hx + (((s & 1) * 2 + c_layer) * 16 + c_clip) * 2048);
+            _Float16* hrow = reinterpret_cast<_Float16*>(hx + (((DF ? s % 3 : s & 1) * 2 + c_layer) * 16 + c_clip) * 2048);
             const _Float16 hh = (_Float16)h;
-            hrow[(j >> 5) * 64 + (j & 31)] = hh;
-            hrow[(j >> 5) * 64 + 32 + (j & 31)] = (_Float16)((h - (float)hh) * 2048.f);
+            const _Float16 hl = (_Float16)((h - (float)hh) * 2048.f);
+            if (DF) __builtin_amdgcn_s_waitcnt(0);                      // the re-mark of this step is in L2
+            hrow[(j >> 5) * 64 + (j & 31)] = DF ? no_mark(hh) : hh;
+            hrow[(j >> 5) * 64 + 32 + (j & 31)] = DF ? no_mark(hl) : hl;
             if (c_layer == 1) {
                 const int t = s - 1;
                 const float yv = h + xs;                                // lstm.py:37-38 skip
@@ -186,25 +271,33 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
                 }
             }
         }
-        // 5. publish: the stores are acknowledged by L2 before this workgroup arrives
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
-        if (tid == 0 && s < L) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!DF) {
+            // 5. publish: the stores are acknowledged by L2 before this workgroup arrives
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            if (tid == 0 && s < L) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     }
 }
 
-size_t lstm_persist_hx_bytes() { return (size_t)8 * 2 * 2 * 16 * 2048; }
+size_t lstm_persist_hx_bytes() { return (size_t)8 * 3 * 2 * 16 * 2048; }
 size_t lstm_persist_ctl_bytes() { return 1024 * sizeof(unsigned); }
 
 int launch_lstm_persist(const LstmPersistArgs& a, hipStream_t stream) {
     if (a.H != 512) { set_error("lstm_persist: built for hidden size 512"); return -1; }
     if (a.B < 1 || a.Bx < 1 || a.Bx > 16 || 8 * a.Bx < a.B) { set_error("lstm_persist: at most 16 clips per XCD (B <= 128)"); return -1; }
     static PerDeviceOnce attr_once;
-    const size_t smem = (size_t)16 * HPITCH + (size_t)3 * 4 * 16 * 17 * sizeof(float) + (size_t)PW * NLDS * 1024;
-    if (attr_once.first())
-        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    constexpr size_t smem = (size_t)16 * HPITCH + (size_t)3 * 4 * 16 * 17 * sizeof(float) + (size_t)PW * NLDS * 1024;
+    static_assert(smem + 64 <= 160 * 1024, "LDS budget");
+    if (attr_once.first()) {
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)smem));
-    hipLaunchKernelGGL(lstm_persist_kernel, dim3(256), dim3(64 * PW), smem, stream, a);
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)smem));
+    }
+    // the caller has filled hx and ctl with 0xFF bytes (data-flag form) or zeros (counter form)
+    if (a.data_flag) hipLaunchKernelGGL(lstm_persist_kernel<true>, dim3(256), dim3(64 * PW), smem, stream, a);
+    else hipLaunchKernelGGL(lstm_persist_kernel<false>, dim3(256), dim3(64 * PW), smem, stream, a);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }
