@@ -403,12 +403,28 @@ def test_seanet_decoder():
     assert rel_l2(got.cpu().numpy(), want.numpy()) < WAV_REL_TOL
 
 
+@pytest.mark.parametrize("arch", ["hop600", "hop320"])
+def test_seanet_decoder_small_and_odd_shapes(arch):
+    """SEANetDecoder against the oracle on one- and two-frame inputs (every transposed conv is all edge), odd batch
+    sizes, both architectures (stride sets 6,5,5,4 and 8,5,4,2)."""
+    m, sd = _model(arch, with_seanet_decoder=True)
+    orc = _oracle(arch, sd)
+    for i, (B, L) in enumerate(((1, 1), (2, 2), (5, 7), (3, 41))):
+        z = torch.randn(B, 512, L, generator=torch.Generator().manual_seed(70 + i)) * 0.6
+        with torch.inference_mode():
+            want = orc.seanet_decoder(z)
+        got = m.feature_extractor.encodec.decoder(z.cuda())
+        assert tuple(got.shape) == tuple(want.shape), (B, L)
+        assert rel_l2(got.cpu().numpy(), want.numpy()) < WAV_REL_TOL, (B, L)
+
+
 def test_persistent_lstm_matches_step_lstm(gpu_model):
     """The one-launch LSTM (per-XCD clip groups, XCD-local step barrier) against the launch-per-step kernel: same
-    codes, features equal, waveform to rounding; batch sizes that leave XCDs empty, partly filled and full."""
+    codes, features equal, waveform to rounding; batch sizes that leave XCDs empty, partly filled and full (100: the
+    last XCD holds 9 of 13 clip rows; 128: 16 per XCD, the state is polled in two rounds)."""
     name, m, sd = gpu_model
     from wavtokenizer_amd import synth
-    for B in (1, 3, 8, 20, 64):
+    for B in (1, 3, 8, 20, 64, 100, 128):
         wav = torch.from_numpy(synth.make_clips(B, 7200 if B > 8 else 24000, seed=500 + B)).cuda()
         f1, c1 = m.encode_infer(wav, bandwidth_id=BW)
         m.set_lstm_mode("step")

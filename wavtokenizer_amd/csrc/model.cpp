@@ -562,6 +562,17 @@ static int build_splits(wt_model* M) {
     if (int rc = add_s32(M, M->at_Wqk, 2L * D * D)) return rc;
     if (int rc = add_s32(M, M->at_Wv, (long)D * D)) return rc;
     if (int rc = add_s32(M, M->at_Wp, (long)D * D)) return rc;
+    if (M->has_seadec) {
+        if (int rc = conv32(M->sd_first)) return rc;
+        if (int rc = add_s32(M, M->sd_lstm.Wih0, 4L * M->H * M->H)) return rc;
+        for (const SeaDecStage& st : M->sd_stages) {
+            if (st.tr_wp && st.cin % 16 == 0) if (int rc = add_s32(M, st.tr_wp, (long)st.r * st.cout * 2 * st.cin)) return rc;
+            if (resblock_fusable(st.cout)) continue;            // its convs run inside resblock16
+            if (int rc = conv32(st.sc)) return rc;
+            if (int rc = conv32(st.c3)) return rc;
+            if (int rc = conv32(st.c1)) return rc;
+        }
+    }
     for (const ResStage& st : M->stages) {
         if (int rc = conv(st.down)) return rc;
         if (int rc = conv(st.sc)) return rc;
@@ -887,19 +898,21 @@ static int plan_lstm(wt_plan* P, const LstmW& w, int B, int L, int H, int xin, c
 // Unfused SEANetResnetBlock with every operand pre-split: x arrives as S32(x) (shortcut) and S32(elu(x)) (conv3),
 // the hidden activation and the output are written as S32(elu(.)); returns the output buffer
 static int plan_resblock_s32(wt_plan* P, const ConvW& c3, const ConvW& c1, const ConvW& sc, int B, long T, int x_raw,
-                             int x_elu, const std::string& name) {
+                             int x_elu, const std::string& name, long x_off = 0, long x_bstride = 0) {
     const int C = sc.cout;
     const int h = P->buf(name + ".h", (size_t)B * T * (C / 2));
     const int y = P->buf(name + ".sc", (size_t)B * T * C);
     const int o = P->buf(name, (size_t)B * T * C);
     GemmArgs a3 = sconv_args(c3, B, T, 1, 1);
     P->step({x_elu, h}, [=](const RunCtx& c) {
-        GemmArgs a = a3; a.A = P->ptr(c, x_elu); a.C = P->ptr(c, h);
+        GemmArgs a = a3; a.A = P->ptr(c, x_elu) + x_off; a.C = P->ptr(c, h);
+        if (x_bstride) a.a_bstride = x_bstride;
         return gemm_s32(P, a, EPI_BIAS_ELU, OUT_S32, c.stream);
     });
     GemmArgs as = sconv_args(sc, B, T, 1, 1);
     P->step({x_raw, y}, [=](const RunCtx& c) {
-        GemmArgs a = as; a.A = P->ptr(c, x_raw); a.C = P->ptr(c, y);
+        GemmArgs a = as; a.A = P->ptr(c, x_raw) + x_off; a.C = P->ptr(c, y);
+        if (x_bstride) a.a_bstride = x_bstride;
         return gemm_s32(P, a, EPI_BIAS, OUT_F32, c.stream);
     });
     GemmArgs a1 = sconv_args(c1, B, T, 1, 1);
@@ -1277,10 +1290,77 @@ static int build_head(wt_plan* P) {
     return 0;
 }
 
+// SEANetDecoder on S32 operands (the default): every GEMM operand is written pre-split by its producer, as in
+// build_encode.  z -> S32 -> conv k7 (fp32 for the LSTM skip + S32 for its input projection) -> LSTM (S32(elu) out)
+// -> per stage: transposed conv as r phase GEMMs over (x[t-1], x[t]) -> resblock (fused resblock16 reads fp32 and
+// writes S32(elu); an unfused one reads S32 raw + S32 elu, both written by the phase GEMM) -> ... -> last conv.
+static bool seadec_s32_ok(const wt_plan* P) {
+    const wt_model* M = P->model;
+    if (!plan_s32(P) || M->sd_stages.empty() || !M->s32.count(M->sd_first.w) || !M->s32.count(M->sd_lstm.Wih0)) return false;
+    for (const SeaDecStage& st : M->sd_stages) {
+        if (!st.tr_wp || !M->s32.count(st.tr_wp) || st.cout % 32) return false;
+        if (!resblock_fusable(st.cout) && !(M->s32.count(st.c3.w) && M->s32.count(st.c1.w) && M->s32.count(st.sc.w))) return false;
+    }
+    return resblock_fusable(M->sd_stages.back().cout);      // the last conv reads fp32
+}
+
+static int build_seanet_decoder_s32(wt_plan* P) {
+    const wt_model* M = P->model;
+    const int B = P->B, L = (int)P->L, H = M->H;
+    const int x0 = P->buf("sdec.in", (size_t)B * L * 512);
+    P->step({x0}, [=](const RunCtx& c) { return launch_transpose(c.in_f, P->ptr(c, x0), B, 512, L, c.stream, 1); });
+    const int xf = P->buf("sdec.0", (size_t)B * L * H);
+    const int xs = P->buf("sdec.0.s32", (size_t)B * L * H);
+    GemmArgs a0 = sconv_args(M->sd_first, B, L, 1, 1);
+    P->step({x0, xf, xs}, [=](const RunCtx& c) {
+        GemmArgs a = a0; a.A = P->ptr(c, x0); a.C = P->ptr(c, xf); a.C2 = P->ptr(c, xs);
+        return gemm_s32(P, a, EPI_BIAS, OUT_F32_AND_S32, c.stream);
+    });
+    int x = plan_lstm(P, M->sd_lstm, B, L, H, xf, "sdec.1", true, xs, true);        // S32(elu(lstm(x) + x))
+    long Tc = L;
+    int di = 2;
+    for (size_t si = 0; si < M->sd_stages.size(); ++si) {
+        const SeaDecStage st = M->sd_stages[si];
+        const long To = Tc * st.r;
+        const int xin = x;
+        const int Tin = (int)Tc;
+        const bool fused = resblock_fusable(st.cout);
+        const bool last = si + 1 == M->sd_stages.size();
+        // SConvTranspose1d (conv.py:232-253), k = 2*stride: see build_seanet_decoder
+        const int trim_l = (st.k - st.r) - (st.k - st.r) / 2;
+        const size_t ynum = (size_t)B * (Tin + 1) * st.r * st.cout;
+        const int y = P->buf("sdec." + std::to_string(di + 1), ynum);
+        const int y2 = fused ? -1 : P->buf("sdec." + std::to_string(di + 1) + ".elu", ynum);
+        const long y_off = (long)trim_l * st.cout, y_bs = (long)(Tin + 1) * st.r * st.cout;
+        P->step({xin, y, y2}, [=](const RunCtx& c) {
+            GemmArgs a;
+            a.A = P->ptr(c, xin); a.a_bstride = (long)Tin * st.cin; a.a_rstride = st.cin;
+            a.T_in = Tin; a.T_out = Tin + 1; a.Cin = st.cin; a.taps = 2; a.pad_left = 1; a.pad_mode = PAD_ZERO;
+            a.W = st.tr_wp; a.w_rstride = 2L * st.cin; a.zW = (long)st.cout * 2 * st.cin; a.bias = st.tr_b;
+            a.M = B * (Tin + 1); a.N = st.cout; a.K = 2 * st.cin;
+            a.C = P->ptr(c, y); a.c_rstride = (long)st.r * st.cout; a.zC = st.cout; a.nz = st.r;
+            if (y2 >= 0) a.C2 = P->ptr(c, y2);
+            return gemm_s32(P, a, EPI_BIAS, fused ? OUT_F32 : OUT_S32_DUAL_ELU, c.stream);
+        }, 1, "sdec.convtr");
+        if (fused)
+            x = plan_resblock(P, st.c3, st.c1, st.sc, B, To, y, "sdec." + std::to_string(di + 2), true, nullptr, y_off, y_bs, !last);
+        else
+            x = plan_resblock_s32(P, st.c3, st.c1, st.sc, B, To, y, y2, "sdec." + std::to_string(di + 2), y_off, y_bs);
+        Tc = To; di += 3;
+    }
+    const int xin = x;
+    const long Tf = Tc;
+    P->step({xin}, [=](const RunCtx& c) {
+        return launch_conv_last(P->ptr(c, xin), M->sd_last_w, M->sd_last_b, c.out_f, B, Tf, 32, 7, 0, c.stream);
+    }, 1, "sdec.last");
+    return 0;
+}
+
 static int build_seanet_decoder(wt_plan* P) {
     const wt_model* M = P->model;
     if (!M->has_seadec) { set_error("checkpoint holds no SEANetDecoder weights"); return WT_ERR_MISSING_TENSOR; }
     const int B = P->B, L = (int)P->L, H = M->H;
+    if (seadec_s32_ok(P)) return build_seanet_decoder_s32(P);
     const int x0 = P->buf("sdec.in", (size_t)B * L * 512);
     P->step({x0}, [=](const RunCtx& c) { return launch_transpose(c.in_f, P->ptr(c, x0), B, 512, L, c.stream); });
     int x = P->buf("sdec.0", (size_t)B * L * H);

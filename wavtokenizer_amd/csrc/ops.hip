@@ -121,12 +121,67 @@ __global__ __launch_bounds__(256) void conv_last_kernel(const float* __restrict_
     }
 }
 
+// The shape the model has (32 channels, k = 7): 256 consecutive output samples per workgroup; their 262 input frames
+// go through LDS once (coalesced 128-byte rows, reflect / zero padding resolved at the fill), then one thread forms
+// one sample from 7 rows x 32 channels (row pitch 36 floats: the 16-byte reads of 16 neighbouring threads cover all
+// banks).  Every input byte crosses the vector memory path once instead of seven times.
+__global__ __launch_bounds__(256) void conv_last32_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y,
+                                                          int T, int Tp, int elu_in) {
+    constexpr int K = 7, C = 32, PITCH = 36, ROWS = 256 + K - 1;
+    __shared__ __attribute__((aligned(16))) float tile[ROWS * PITCH];
+    __shared__ __attribute__((aligned(16))) float wl[K * C];
+    const int tid = threadIdx.x;
+    const long b = blockIdx.y;
+    const int t0 = blockIdx.x * 256;
+    const int pl = (K - 1) - (K - 1) / 2;
+    if (tid < K * C) wl[tid] = w[tid];
+    const int rows = T - t0 + K - 1 < ROWS ? T - t0 + K - 1 : ROWS;       // rows that an output t < T reads
+    for (int e = tid; e < rows * (C / 4); e += 256) {
+        const int r = e >> 3, c4 = e & 7;
+        bool ok;
+        const int pos = reflect_pos(t0 - pl + r, T, Tp, ok);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok && pos >= 0) {
+            v = *reinterpret_cast<const f32x4*>(x + (b * T + pos) * C + c4 * 4);
+            if (elu_in) {
+                v.x = v.x > 0.f ? v.x : __expf(v.x) - 1.f;
+                v.y = v.y > 0.f ? v.y : __expf(v.y) - 1.f;
+                v.z = v.z > 0.f ? v.z : __expf(v.z) - 1.f;
+                v.w = v.w > 0.f ? v.w : __expf(v.w) - 1.f;
+            }
+        }
+        *reinterpret_cast<f32x4*>(tile + r * PITCH + c4 * 4) = v;
+    }
+    __syncthreads();
+    const int t = t0 + tid;
+    if (t >= T) return;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        float aj = 0.f;
+#pragma unroll
+        for (int c4 = 0; c4 < C / 4; ++c4) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(tile + (tid + j) * PITCH + c4 * 4);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + j * C + c4 * 4);       // same address in every lane: broadcast
+            aj += (xv.x * wv.x + xv.y * wv.y) + (xv.z * wv.z + xv.w * wv.w);
+        }
+        acc += aj;
+    }
+    y[b * T + t] = acc + bias[0];
+}
+
 int launch_conv_last(const float* x, const float* w, const float* bias, float* y, int B, long T, int Cin, int k,
                      int elu_in, hipStream_t s) {
     const long BT = (long)B * T;
     const int pl = (k - 1) - (k - 1) / 2, pr = (k - 1) / 2;
     const int maxpad = pl > pr ? pl : pr;
     const int Tp = T > maxpad ? (int)T : maxpad + 1;
+    if (Cin == 32 && k == 7 && B <= 65535) {
+        hipLaunchKernelGGL(conv_last32_kernel, dim3((unsigned)((T + 255) / 256), B), dim3(256), 0, s, x, w, bias, y, (int)T, Tp, elu_in);
+        WT_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (Cin < 4 || Cin > 256 || (Cin & (Cin - 1))) { set_error("conv_last: Cin must be a power of two in [4, 256]"); return -1; }
     const long groups = (BT + (256 / (Cin / 4)) - 1) / (256 / (Cin / 4));
     int blocks = (int)(groups < 16384 ? groups : 16384);
