@@ -10,7 +10,8 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwavtok_hip.so")
+# WAVTOK_HIP_LIB names another build of the same library (A/B timing of two kernel versions); never a fallback
+LIB_PATH = os.environ.get("WAVTOK_HIP_LIB") or os.path.join(_HERE, "libwavtok_hip.so")
 
 # every symbol include/wavtokenizer_amd.h declares
 EXPORTS = [

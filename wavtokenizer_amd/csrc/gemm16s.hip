@@ -56,6 +56,35 @@ __device__ __forceinline__ float erf_s(float a) {
     return t > 0.927734375f ? big : small;
 }
 __device__ __forceinline__ float gelu_erf_s(float x) { return x * 0.5f * (1.f + erf_s(x * 0.70710678118654752440f)); }
+// the same arithmetic on two elements at a time: every polynomial step is one v_pk_fma_f32 / v_pk_mul_f32
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 gelu_erf_s2(f32x2 x) {
+    const f32x2 a = x * 0.70710678118654752440f;
+    const f32x2 t = __builtin_elementwise_abs(a), s = a * a;
+    f32x2 r = fma2((f32x2)(-1.72853470e-5f), t, (f32x2)(3.83197126e-4f));
+    const f32x2 u = fma2((f32x2)(-3.88396438e-3f), t, (f32x2)(2.42546219e-2f));
+    r = fma2(r, s, u);
+    r = fma2(r, t, (f32x2)(-1.06777877e-1f));
+    r = fma2(r, t, (f32x2)(-6.34846687e-1f));
+    r = fma2(r, t, (f32x2)(-1.28717512e-1f));
+    r = fma2(r, t, -t);
+    f32x2 q = fma2((f32x2)(-5.96761703e-4f), s, (f32x2)(4.99119423e-3f));
+    q = fma2(q, s, (f32x2)(-2.67681349e-2f));
+    q = fma2(q, s, (f32x2)(1.12819925e-1f));
+    q = fma2(q, s, (f32x2)(-3.76125336e-1f));
+    q = fma2(q, s, (f32x2)(1.28379166e-1f));
+    const f32x2 small = fma2(q, a, a);
+    f32x2 e;
+    e.x = t.x > 0.927734375f ? copysignf(1.0f - __expf(r.x), a.x) : small.x;
+    e.y = t.y > 0.927734375f ? copysignf(1.0f - __expf(r.y), a.y) : small.y;
+    const f32x2 hx = x * 0.5f;
+    return fma2(hx, e, hx);
+}
+__device__ __forceinline__ f32x4 gelu_erf_s4(f32x4 v) {
+    const f32x2 lo = gelu_erf_s2((f32x2){v.x, v.y}), hi = gelu_erf_s2((f32x2){v.z, v.w});
+    return (f32x4){lo.x, lo.y, hi.x, hi.y};
+}
 
 // fp32 value -> S32 slots of element n (n & 31 = slot) in the group that starts at `grp` (a _Float16*)
 __device__ __forceinline__ void store_s32(_Float16* grp, int slot, float v) {
@@ -416,7 +445,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
                             if (EPI == EPI_BIAS_ELU || (OUT == OUT_S32_DUAL_ELU && pz == 1)) {
                                 v.x = elu_s(v.x); v.y = elu_s(v.y); v.z = elu_s(v.z); v.w = elu_s(v.w);
                             } else if (EPI == EPI_BIAS_GELU) {
-                                v.x = gelu_erf_s(v.x); v.y = gelu_erf_s(v.y); v.z = gelu_erf_s(v.z); v.w = gelu_erf_s(v.w);
+                                v = gelu_erf_s4(v);
                             }
                             if (as_f32) {
                                 const int ch = 2 * g + (col_h >> 2);
@@ -474,7 +503,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
                     } else if (EPI == EPI_BIAS_ELU) {
                         v.x = elu_s(v.x); v.y = elu_s(v.y); v.z = elu_s(v.z); v.w = elu_s(v.w);
                     } else if (EPI == EPI_BIAS_GELU) {
-                        v.x = gelu_erf_s(v.x); v.y = gelu_erf_s(v.y); v.z = gelu_erf_s(v.z); v.w = gelu_erf_s(v.w);
+                        v = gelu_erf_s4(v);
                     } else if (EPI == EPI_BIAS_GAMMA_RES) {
                         const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + n);
                         v = *reinterpret_cast<const f32x4*>(p.R + (long)m * p.r_rstride + n) + gm * v;
