@@ -441,7 +441,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
                         for (int g = 0; g < 4; ++g) {
                             const int n = n0 + 8 * g + col_h;
                             f32x4 v = acc4(i, j, g);
-                            if (p.bias && n < p.N) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                            if (p.bias && n < p.N && !(p.dbg & 256)) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                            if (EPI == EPI_BIAS_GELU && (p.dbg & 512)) {
+                            } else
                             if (EPI == EPI_BIAS_ELU || (OUT == OUT_S32_DUAL_ELU && pz == 1)) {
                                 v.x = elu_s(v.x); v.y = elu_s(v.y); v.z = elu_s(v.z); v.w = elu_s(v.w);
                             } else if (EPI == EPI_BIAS_GELU) {
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
                             f32x4 q = *reinterpret_cast<const f32x4*>(sc + r * 128 + ((ch ^ ((r >> 1) & 7)) * 16));
                             const int m = m_w + i * 32 + r;
                             const int n = n0 + 4 * ch;             // fp32 columns; S32: byte ch * 16 of the group at n0
-                            if (m < p.M && (!as_f32 || n < p.N)) {
+                            if (m < p.M && (!as_f32 || n < p.N) && !(p.dbg & 128)) {
                                 float* dst = dbase + (long)m * p.c_rstride + n;
                                 *reinterpret_cast<f32x4*>(dst) = q;
                             }
