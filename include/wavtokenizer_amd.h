@@ -73,6 +73,10 @@ typedef enum {
 enum {
     WT_PLAN_FLAG_KEEP_STAGES = 1,  /* never alias stage buffers (debug taps; bigger workspace) */
     WT_PLAN_FLAG_STEP_LSTM = 4,    /* LSTM as one launch per time step instead of the persistent per-XCD kernel */
+    WT_PLAN_FLAG_GRAPH = 8,        /* small batches: the second call in a row with the same buffers records the plan's
+                                      launches as a hipGraph, later calls with those buffers replay it (one
+                                      hipGraphLaunch on the caller's stream); any other call launches directly.  Such a
+                                      plan must not be run from two host threads at once */
     WT_PLAN_FLAG_FP32_GEMM = 2     /* every dense layer on the fp32 MFMA chain; default: the fp32-equivalent
                                       split-f16 kernel (3 f16 MFMAs per product, fp32 accumulate) where covered */
 };
@@ -96,6 +100,8 @@ void   wt_plan_destroy(wt_plan* p);
 size_t wt_plan_workspace_bytes(const wt_plan* p);
 int64_t wt_plan_frames(const wt_plan* p);             /* L = ceil(T / hop) (conv.py:54-61) */
 int    wt_plan_num_launches(const wt_plan* p);
+/* calls of this plan that were served by a graph replay (WT_PLAN_FLAG_GRAPH); 0 for a plan without the flag */
+int64_t wt_plan_graph_replays(const wt_plan* p);
 /* Debug taps: byte offset / element count of a named stage buffer inside the workspace. */
 int    wt_plan_find_buffer(const wt_plan* p, const char* name, size_t* offset, size_t* numel);
 int    wt_plan_buffer_name(const wt_plan* p, int32_t index, const char** name);

@@ -474,7 +474,7 @@ def test_plan_introspection_and_timing_hook(gpu_model):
     feats, _ = m.encode_infer(wav, bandwidth_id=BW)
     m.decode(feats, bandwidth_id=BW)
     L = feats.shape[-1]
-    plan = m._engine.plans[(_capi.WT_PLAN_DECODE, 2, L, 0)][0]
+    plan = m._engine.plans[(_capi.WT_PLAN_DECODE, 2, L, m._graph_flags(2))][0]
     n = _capi.lib.wt_plan_num_steps(plan)
     names = []
     for i in range(n):
@@ -495,3 +495,36 @@ def test_plan_introspection_and_timing_hook(gpu_model):
     assert _capi.lib.wt_plan_find_buffer(plan, b"bb.out", ctypes.byref(off), ctypes.byref(numel)) == 0
     assert numel.value == 2 * L * m.arch.dim
     assert _capi.lib.wt_plan_find_buffer(plan, b"no.such.buffer", ctypes.byref(off), ctypes.byref(numel)) != 0
+
+
+def test_graph_replay_matches_direct_launches(gpu_model):
+    """Small batches replay a recorded hipGraph (WT_PLAN_FLAG_GRAPH): first call direct, second call records, later calls
+    replay.  Results must be bit-identical to direct launches, for fresh inputs too (the graph reads fixed staging
+    buffers), and the replay counter must show that the graph really served the calls."""
+    from wavtokenizer_amd import _capi, synth
+    name, m, _sd = gpu_model
+    B, T = 3, 9000
+    wavs = [torch.from_numpy(synth.make_clips(B, T, seed=900 + i)).cuda() for i in range(4)]
+    m.set_graph_max_clips(0)
+    try:
+        want = []
+        for w in wavs:
+            f, c = m.encode_infer(w, bandwidth_id=BW)
+            want.append((f, c, m.decode(f, bandwidth_id=BW)))
+    finally:
+        m.set_graph_max_clips(16)
+    for w, (f0, c0, o0) in zip(wavs, want):
+        f, c = m.encode_infer(w, bandwidth_id=BW)
+        o = m.decode(f, bandwidth_id=BW)
+        assert torch.equal(c, c0) and torch.equal(f, f0) and torch.equal(o, o0)
+    L = want[0][0].shape[-1]
+    flags = m._graph_flags(B)
+    assert flags & _capi.WT_PLAN_FLAG_GRAPH
+    eplan = m._engine.plans[(_capi.WT_PLAN_ENCODE, B, T, flags)][0]
+    dplan = m._engine.plans[(_capi.WT_PLAN_DECODE, B, L, flags)][0]
+    assert _capi.lib.wt_plan_graph_replays(eplan) >= 3 and _capi.lib.wt_plan_graph_replays(dplan) >= 3
+    # results handed out earlier are copies: a later call must not change them
+    f1, c1 = m.encode_infer(wavs[0], bandwidth_id=BW)
+    keep = f1.clone()
+    m.encode_infer(wavs[1], bandwidth_id=BW)
+    assert torch.equal(f1, keep)

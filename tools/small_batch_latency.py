@@ -17,6 +17,15 @@ for B in (1, 4, 16):
     t0 = time.perf_counter()
     for _ in range(20):
         f, c = m.encode_infer(wav, bandwidth_id=bw); o = m.decode(f, bandwidth_id=bw)
+    th = (time.perf_counter() - t0) / 20            # host time to enqueue one round trip
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 20
-    print(f"B={B}: {dt*1e3:.2f} ms per round trip = {B*3/dt:.0f} audio-s/s", flush=True)
+    # one call at a time (what a latency-sensitive caller sees)
+    lat = []
+    for _ in range(10):
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        f, c = m.encode_infer(wav, bandwidth_id=bw); o = m.decode(f, bandwidth_id=bw)
+        torch.cuda.synchronize(); lat.append(time.perf_counter() - t1)
+    lat.sort()
+    print(f"B={B}: {dt*1e3:.2f} ms per round trip back to back = {B*3/dt:.0f} audio-s/s; host enqueue {th*1e3:.2f} ms; "
+          f"single-call latency p50 {lat[len(lat)//2]*1e3:.2f} ms", flush=True)

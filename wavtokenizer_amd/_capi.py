@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("WAVTOK_HIP_LIB") or os.path.join(_HERE, "libwavtok_hi
 # every symbol include/wavtokenizer_amd.h declares
 EXPORTS = [
     "wt_last_error", "wt_version", "wt_model_create", "wt_model_destroy", "wt_model_hop", "wt_model_weight_bytes",
-    "wt_plan_create", "wt_plan_destroy", "wt_plan_workspace_bytes", "wt_plan_frames", "wt_plan_num_launches",
+    "wt_plan_create", "wt_plan_destroy", "wt_plan_workspace_bytes", "wt_plan_frames", "wt_plan_num_launches", "wt_plan_graph_replays",
     "wt_plan_find_buffer", "wt_plan_buffer_name", "wt_plan_num_steps", "wt_plan_step_name", "wt_plan_set_timing",
     "wt_plan_read_timing", "wt_encode", "wt_codes_to_features", "wt_decode",
     "wt_seanet_decode", "wt_head", "wt_sconv1d", "wt_linear", "wt_conv1d_s32", "wt_vq_workspace_bytes", "wt_vq_nearest",
@@ -28,6 +28,7 @@ WT_PLAN_ENCODE, WT_PLAN_DECODE, WT_PLAN_SEANET_DECODER, WT_PLAN_HEAD = 0, 1, 2, 
 WT_PLAN_FLAG_KEEP_STAGES = 1
 WT_PLAN_FLAG_FP32_GEMM = 2
 WT_PLAN_FLAG_STEP_LSTM = 4
+WT_PLAN_FLAG_GRAPH = 8
 
 
 class WtArch(ctypes.Structure):
@@ -67,6 +68,8 @@ def _load() -> ctypes.CDLL:
     lib.wt_plan_frames.argtypes = [c_void_p]
     lib.wt_plan_frames.restype = c_int64
     lib.wt_plan_num_launches.argtypes = [c_void_p]
+    lib.wt_plan_graph_replays.argtypes = [c_void_p]
+    lib.wt_plan_graph_replays.restype = c_int64
     lib.wt_plan_find_buffer.argtypes = [c_void_p, c_char_p, POINTER(c_size_t), POINTER(c_size_t)]
     lib.wt_plan_buffer_name.argtypes = [c_void_p, c_int32, POINTER(c_char_p)]
     lib.wt_plan_num_steps.argtypes = [c_void_p]

@@ -153,6 +153,7 @@ class _Engine:
     def __init__(self):
         self.model = ctypes.c_void_p()
         self.plans: Dict[Tuple[int, int, int, int], Tuple[ctypes.c_void_p, torch.Tensor]] = {}
+        self.io: Dict[Tuple[int, int, int, int], Dict[str, torch.Tensor]] = {}     # fixed I/O buffers of graph plans
         self.device_index = -1
         self._keepalive: List[Any] = []
 
@@ -160,6 +161,7 @@ class _Engine:
         for plan, _ws in self.plans.values():
             lib.wt_plan_destroy(plan)
         self.plans.clear()
+        self.io.clear()
         if self.model:
             lib.wt_model_destroy(self.model)
             self.model = ctypes.c_void_p()
@@ -201,11 +203,21 @@ class _Engine:
         if len(self.plans) >= 8:                      # small LRU: drop the oldest plan + workspace
             old = next(iter(self.plans))
             lib.wt_plan_destroy(self.plans.pop(old)[0])
+            self.io.pop(old, None)
         p = ctypes.c_void_p()
         check(lib.wt_plan_create(self.model, kind, B, length, flags, ctypes.byref(p)), "wt_plan_create")
         ws = torch.empty(lib.wt_plan_workspace_bytes(p), dtype=torch.uint8, device=device)
         self.plans[key] = (p, ws)
         return p, ws
+
+    def staging(self, kind: int, B: int, length: int, flags: int, make) -> Dict[str, torch.Tensor]:
+        """Fixed input/output tensors of a graph plan: a recorded hipGraph replays fixed addresses, so calls copy their
+        input in and hand out copies of the results (a few hundred KB at the batch sizes graphs are used for)."""
+        key = (kind, B, length, flags)
+        io = self.io.get(key)
+        if io is None:
+            io = self.io[key] = make()
+        return io
 
 
 def _stream_ptr(device: torch.device) -> ctypes.c_void_p:
@@ -230,6 +242,9 @@ class WavTokenizer(nn.Module):
         self._engine = _Engine()
         self._dirty = True
         self._plan_flags = 0
+        # batches up to this many clips are replayed as one hipGraph per (shape) plan: they are bound by the host's
+        # launch rate (about 100 launches per call), not by the GPU; 0 turns graphs off
+        self._graph_max_clips = int(os.environ.get("WAVTOK_GRAPH_MAX_CLIPS", "16"))
         for m in (feature_extractor, backbone, head):
             m._bind(self)
 
@@ -354,6 +369,15 @@ class WavTokenizer(nn.Module):
         self._plan_flags = (self._plan_flags | _capi.WT_PLAN_FLAG_FP32_GEMM) if mode == "f32" else \
             (self._plan_flags & ~_capi.WT_PLAN_FLAG_FP32_GEMM)
 
+    def set_graph_max_clips(self, n: int):
+        """Largest batch whose encode / decode plans are recorded and replayed as a hipGraph (default 16; 0 = never)."""
+        self._graph_max_clips = int(n)
+
+    def _graph_flags(self, B: int) -> int:
+        if 0 < B <= self._graph_max_clips and not (self._plan_flags & _capi.WT_PLAN_FLAG_KEEP_STAGES):
+            return self._plan_flags | _capi.WT_PLAN_FLAG_GRAPH
+        return self._plan_flags
+
     def set_lstm_mode(self, mode: str):
         """"persistent" (default): the whole LSTM recurrence in one launch (per-XCD clip groups, weights resident);
         "step": one launch per time step."""
@@ -396,8 +420,19 @@ class WavTokenizer(nn.Module):
         assert audio.dim() == 2, "expected audio of shape (B, T)"
         audio = self._as_input(audio, dev)
         B, T = audio.shape
-        plan, ws = self._engine.plan(_capi.WT_PLAN_ENCODE, B, T, self._plan_flags, dev)
+        flags = self._graph_flags(B)
+        plan, ws = self._engine.plan(_capi.WT_PLAN_ENCODE, B, T, flags, dev)
         L = int(lib.wt_plan_frames(plan))
+        if flags & _capi.WT_PLAN_FLAG_GRAPH:
+            io = self._engine.staging(_capi.WT_PLAN_ENCODE, B, T, flags, lambda: {
+                "in": torch.empty((B, T), dtype=torch.float32, device=dev),
+                "feats": torch.empty((B, 512, L), dtype=torch.float32, device=dev),
+                "codes": torch.empty((1, B, L), dtype=torch.int64, device=dev),
+                "emb": torch.empty((B, 512, L), dtype=torch.float32, device=dev)})
+            io["in"].copy_(audio)
+            check(lib.wt_encode(plan, _ptr(io["in"]), _ptr(io["feats"]), _ptr(io["codes"]), _ptr(io["emb"]), _ptr(ws),
+                                _stream_ptr(dev)), "wt_encode")
+            return io["feats"].clone(), io["codes"].clone(), (io["emb"].clone() if want_emb else None)
         feats = torch.empty((B, 512, L), dtype=torch.float32, device=dev)
         codes = torch.empty((1, B, L), dtype=torch.int64, device=dev)
         emb = torch.empty((B, 512, L), dtype=torch.float32, device=dev) if want_emb else None
@@ -420,7 +455,15 @@ class WavTokenizer(nn.Module):
         bw = self._bandwidth_index(bandwidth_id)
         features = self._as_input(features, dev)
         B, _, L = features.shape
-        plan, ws = self._engine.plan(_capi.WT_PLAN_DECODE, B, L, self._plan_flags, dev)
+        flags = self._graph_flags(B) if not want_backbone else self._plan_flags
+        plan, ws = self._engine.plan(_capi.WT_PLAN_DECODE, B, L, flags, dev)
+        if flags & _capi.WT_PLAN_FLAG_GRAPH:
+            io = self._engine.staging(_capi.WT_PLAN_DECODE, B, L, flags, lambda: {
+                "in": torch.empty((B, self._arch.input_channels, L), dtype=torch.float32, device=dev),
+                "wav": torch.empty((B, L * self._arch.hop_length), dtype=torch.float32, device=dev)})
+            io["in"].copy_(features)
+            check(lib.wt_decode(plan, _ptr(io["in"]), bw, _ptr(io["wav"]), _ptr(None), _ptr(ws), _stream_ptr(dev)), "wt_decode")
+            return io["wav"].clone(), None
         wav = torch.empty((B, L * self._arch.hop_length), dtype=torch.float32, device=dev)
         bb = torch.empty((B, L, self._arch.dim), dtype=torch.float32, device=dev) if want_backbone else None
         check(lib.wt_decode(plan, _ptr(features), bw, _ptr(wav), _ptr(bb), _ptr(ws), _stream_ptr(dev)), "wt_decode")
