@@ -9,7 +9,7 @@ m = WavTokenizer.from_arch(arch)
 m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
 m = m.eval().cuda()
 bw = torch.tensor([0])
-for B in [int(b) for b in os.environ.get("WT_SB_BATCHES", "1,4,16").split(",")]:
+for B in [int(b) for b in os.environ.get("WT_SB_BATCHES", "1,4,8,16,32").split(",")]:
     wav = torch.from_numpy(synth.make_clips(B, 72000, seed=5)).cuda()
     for _ in range(3):
         f, c = m.encode_infer(wav, bandwidth_id=bw); o = m.decode(f, bandwidth_id=bw)

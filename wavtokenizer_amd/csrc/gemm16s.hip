@@ -609,13 +609,16 @@ static int launch16s_tiled(const GemmArgs& a, hipStream_t s) {
             case 6: return launch16s_one<128, 192, 4, 2, 2, EPI, OUT>(a, s);
             case 7: return launch16s_one<256, 128, 4, 2, 3, EPI, OUT>(a, s);
             case 8: return launch16s_one<128, 32, 4, 1, 3, EPI, OUT>(a, s);
+            case 9: return launch16s_one<128, 64, 4, 1, 3, EPI, OUT>(a, s);
             default: break;
         }
         if (a.N <= 64) return launch16s_one<256, 64, 8, 1, 3, EPI, OUT>(a, s);      // narrow outputs (down conv 1)
         // a handful of clips (M of a few hundred rows): with 128-column tiles fewer than 32 CUs would each walk the whole
         // K loop alone, so the problem is cut into 32-column tiles instead (4x the workgroups, a third of the work per
         // K step).  Every tile shape accumulates K in the same order: results do not depend on the choice
-        if (((a.M + 127) / 128) * ((a.N + 127) / 128) * a.nz <= 32) return launch16s_one<128, 32, 4, 1, 3, EPI, OUT>(a, s);
+        const long t128 = ((a.M + 127) / 128) * ((a.N + 127) / 128) * a.nz;
+        if (t128 <= 32) return launch16s_one<128, 32, 4, 1, 3, EPI, OUT>(a, s);
+        if (t128 <= 100) return launch16s_one<128, 64, 4, 1, 3, EPI, OUT>(a, s);     // up to ~16 clips: 2x the workgroups
         // one 8-wave workgroup per CU (256 slots): 128x192 unless its last round would be mostly idle
         const long tm = (a.M + 127) / 128;
         auto cost = [&](int bn, double eff) {
