@@ -293,17 +293,18 @@ int launch_gn_stats(const float* x, const float* gamma, const float* beta, float
 // wave per group), and writes the normalised (swish-activated) slab back once, fp32 or S32: one global read and one
 // write per element where gn_stats_kernel makes three strided read passes.
 template <int SWISH>
-__global__ __launch_bounds__(256) void gn_tile_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+__global__ __launch_bounds__(512) void gn_tile_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float* __restrict__ scale,
                                                       float* __restrict__ shift, float* __restrict__ y, int L, int C,
                                                       int cg, int GB, float eps, int s32) {
     extern __shared__ __attribute__((aligned(16))) float tile[];      // [L][W], W = GB * cg
-    __shared__ float s_sc[128], s_sh[128];
+    __shared__ float s_sc[128], s_sh[128], s_red[8];
+    const int NT = blockDim.x;                             // 256, or 512 for slabs so large that one workgroup fills the CU
     const int W = GB * cg, W4 = W / 4;
     const int c0 = blockIdx.x * W, b = blockIdx.y;
     const float* xb = x + (long)b * L * C + c0;
-    // (row, float4) of element e = threadIdx.x + 256 k, advanced without divisions
-    const int dt = 256 / W4, dq = 256 - dt * W4;
+    // (row, float4) of element e = threadIdx.x + NT k, advanced without divisions
+    const int dt = NT / W4, dq = NT - dt * W4;
     {
         int t = threadIdx.x / W4, q = threadIdx.x - t * W4;
         for (; t < L; t += dt, q += dq) {
@@ -312,9 +313,48 @@ __global__ __launch_bounds__(256) void gn_tile_kernel(const float* __restrict__ 
         }
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = NT >> 6;
     const int st = 64 / cg, sj = 64 - st * cg;               // lane stride 64 in (row, channel) steps
-    for (int gl = wv; gl < GB; gl += 4) {                  // one wave per group
+    if (nw == 2 * GB) {
+        // two waves per group, each over half of the rows; the halves meet in LDS in a fixed order
+        const int gl = wv >> 1, part = wv & 1;
+        const int r0 = part ? L / 2 : 0, r1 = part ? L : L / 2;
+        const int n = L * cg;
+        const float* col = tile + gl * cg;
+        float sum = 0.f;
+        {
+            int t = r0 + lane / cg, j = lane - (lane / cg) * cg;
+            for (; t < r1; t += st, j += sj) {
+                if (j >= cg) { j -= cg; ++t; if (t >= r1) break; }
+                sum += col[t * W + j];
+            }
+        }
+        sum = wave_sum(sum);
+        if (lane == 0) s_red[wv] = sum;
+        __syncthreads();
+        const float mean = (s_red[2 * gl] + s_red[2 * gl + 1]) / (float)n;
+        __syncthreads();
+        float sq = 0.f;
+        {
+            int t = r0 + lane / cg, j = lane - (lane / cg) * cg;
+            for (; t < r1; t += st, j += sj) {
+                if (j >= cg) { j -= cg; ++t; if (t >= r1) break; }
+                const float d = col[t * W + j] - mean;
+                sq += d * d;
+            }
+        }
+        sq = wave_sum(sq);
+        if (lane == 0) s_red[wv] = sq;
+        __syncthreads();
+        const float rstd = 1.f / sqrtf((s_red[2 * gl] + s_red[2 * gl + 1]) / (float)n + eps);
+        if (part == 0 && lane < cg) {
+            const int c = c0 + gl * cg + lane;
+            const float sc = rstd * gamma[c], sh = beta[c] - mean * sc;
+            s_sc[gl * cg + lane] = sc; s_sh[gl * cg + lane] = sh;
+            scale[(long)b * C + c] = sc; shift[(long)b * C + c] = sh;
+        }
+    } else
+    for (int gl = wv; gl < GB; gl += nw) {                 // one wave per group
         const int n = L * cg;
         const float* col = tile + gl * cg;
         float sum = 0.f;
@@ -378,8 +418,10 @@ int launch_gn_apply(const float* x, const float* gamma, const float* beta, float
             WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gn_tile_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         }
         dim3 grid(groups / GB, B);
-        if (swish) hipLaunchKernelGGL(gn_tile_kernel<1>, grid, dim3(256), smem, s, x, gamma, beta, scale, shift, y, L, C, cg, GB, eps, out_s32);
-        else hipLaunchKernelGGL(gn_tile_kernel<0>, grid, dim3(256), smem, s, x, gamma, beta, scale, shift, y, L, C, cg, GB, eps, out_s32);
+        // a slab above 48 KB leaves room for one or two workgroups per CU: give each 8 waves (two per group) then
+        const int nt = (smem > 48 * 1024 && GB == 4) ? 512 : 256;
+        if (swish) hipLaunchKernelGGL(gn_tile_kernel<1>, grid, dim3(nt), smem, s, x, gamma, beta, scale, shift, y, L, C, cg, GB, eps, out_s32);
+        else hipLaunchKernelGGL(gn_tile_kernel<0>, grid, dim3(nt), smem, s, x, gamma, beta, scale, shift, y, L, C, cg, GB, eps, out_s32);
         WT_HIP_CHECK(hipGetLastError());
         return 0;
     }
