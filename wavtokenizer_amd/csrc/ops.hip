@@ -314,35 +314,32 @@ __global__ __launch_bounds__(512) void gn_tile_kernel(const float* __restrict__ 
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = NT >> 6;
-    const int st = 64 / cg, sj = 64 - st * cg;               // lane stride 64 in (row, channel) steps
     if (nw == 2 * GB) {
         // two waves per group, each over half of the rows; the halves meet in LDS in a fixed order
         const int gl = wv >> 1, part = wv & 1;
         const int r0 = part ? L / 2 : 0, r1 = part ? L : L / 2;
         const int n = L * cg;
         const float* col = tile + gl * cg;
+        // a lane reads 4 channels of one row per step: 64 / (cg / 4) rows per wave instruction
+        const int cg4 = cg >> 2, rp = 64 / cg4, lr = lane / cg4, lq = lane - lr * cg4;
         float sum = 0.f;
-        {
-            int t = r0 + lane / cg, j = lane - (lane / cg) * cg;
-            for (; t < r1; t += st, j += sj) {
-                if (j >= cg) { j -= cg; ++t; if (t >= r1) break; }
-                sum += col[t * W + j];
+        if (lr < rp)
+            for (int t = r0 + lr; t < r1; t += rp) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(col + t * W + lq * 4);
+                sum += (v.x + v.y) + (v.z + v.w);
             }
-        }
         sum = wave_sum(sum);
         if (lane == 0) s_red[wv] = sum;
         __syncthreads();
         const float mean = (s_red[2 * gl] + s_red[2 * gl + 1]) / (float)n;
         __syncthreads();
         float sq = 0.f;
-        {
-            int t = r0 + lane / cg, j = lane - (lane / cg) * cg;
-            for (; t < r1; t += st, j += sj) {
-                if (j >= cg) { j -= cg; ++t; if (t >= r1) break; }
-                const float d = col[t * W + j] - mean;
-                sq += d * d;
+        if (lr < rp)
+            for (int t = r0 + lr; t < r1; t += rp) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(col + t * W + lq * 4);
+                const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+                sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
             }
-        }
         sq = wave_sum(sq);
         if (lane == 0) s_red[wv] = sq;
         __syncthreads();
@@ -357,24 +354,21 @@ __global__ __launch_bounds__(512) void gn_tile_kernel(const float* __restrict__ 
     for (int gl = wv; gl < GB; gl += nw) {                 // one wave per group
         const int n = L * cg;
         const float* col = tile + gl * cg;
+        const int cg4 = cg >> 2, rp = 64 / cg4, lr = lane / cg4, lq = lane - lr * cg4;
         float sum = 0.f;
-        {
-            int t = lane / cg, j = lane - t * cg;
-            for (; t < L; t += st, j += sj) {
-                if (j >= cg) { j -= cg; ++t; if (t >= L) break; }
-                sum += col[t * W + j];
+        if (lr < rp)
+            for (int t = lr; t < L; t += rp) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(col + t * W + lq * 4);
+                sum += (v.x + v.y) + (v.z + v.w);
             }
-        }
         const float mean = wave_sum(sum) / (float)n;
         float sq = 0.f;
-        {
-            int t = lane / cg, j = lane - t * cg;
-            for (; t < L; t += st, j += sj) {
-                if (j >= cg) { j -= cg; ++t; if (t >= L) break; }
-                const float d = col[t * W + j] - mean;
-                sq += d * d;
+        if (lr < rp)
+            for (int t = lr; t < L; t += rp) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(col + t * W + lq * 4);
+                const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+                sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
             }
-        }
         const float rstd = 1.f / sqrtf(wave_sum(sq) / (float)n + eps);
         if (lane < cg) {
             const int c = c0 + gl * cg + lane;
