@@ -165,7 +165,8 @@ struct LstmPersistArgs {
     unsigned* host_err;   // optional host-mapped word, set to 1 when a step barrier times out
     int B, L, H, Bx;      // Bx = clips per XCD = ceil(B / 8) <= 16
     int elu_out, out_s32;
-    int data_flag;        // 1: the exchanged state carries its own readiness marks (default); 0: arrival counter per step
+    int data_flag;        // bit 0: the exchanged state carries its own readiness marks (default), else arrival counter per step;
+                          // bit 2: workgroup 0 of XCD 0 writes phase timestamps of steps 64..71 into ctl[520..] (tools/lstm_trace.py)
 };
 size_t lstm_persist_hx_bytes();
 size_t lstm_persist_ctl_bytes();

@@ -52,6 +52,10 @@ __device__ __forceinline__ _Float16 no_mark(_Float16 v) {
 // by L2 before the step's data is stored, so whoever sees that data can never see the older contents again).  Per step
 // that is ONE L2 round trip on each side (store; load) instead of store -> acknowledge -> counter atomic -> poll -> load.
 // !DF: the arrival-counter form (two buffers), kept for comparison (WT_LSTM_PERSIST=2).
+// phase timestamps of workgroup 0 of XCD 0, steps 64..71 (WT_LSTM_TRACE=1, tools/lstm_trace.py): 100 MHz ticks into ctl[520..]
+#define LP_TRACE(ph) do { if (tr_on && s >= 64 && s < 72) { \
+    const unsigned long long tt = __builtin_amdgcn_s_memrealtime(); \
+    if (lane == 0) { a.ctl[520 + ((s - 64) * 6 + (ph)) * 2] = (unsigned)tt; a.ctl[521 + ((s - 64) * 6 + (ph)) * 2] = (unsigned)(tt >> 32); } } } while (0)
 template <bool DF>
 __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersistArgs a) {
     constexpr int NBUF = DF ? 3 : 2;
@@ -104,7 +108,9 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
 
     for (int e = tid; e < 16 * HPITCH / 16; e += 64 * PW) reinterpret_cast<f32x4p*>(hst)[e] = (f32x4p){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
+    const bool tr_on = (a.data_flag & 4) && xcc == 0 && w == 0 && __builtin_amdgcn_readfirstlane(wave) == 0;
     for (int s = 0; s <= L; ++s) {
+        LP_TRACE(0);
         // layer-0 input projection of this step (independent of the recurrence): requested before the wait
         float xg[4] = {0.f, 0.f, 0.f, 0.f};
         float xs = 0.f;
@@ -172,7 +178,9 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
                     }
                 }
             }
+            LP_TRACE(1);
             __syncthreads();
+            LP_TRACE(2);
             if (s_stop) return;
             // this workgroup now holds all of step s-1, so every workgroup is past its reads of step s-2: re-mark the
             // own slice of the buffer that held it (it is written again at step s+1)
@@ -237,7 +245,9 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
                 for (int r = 0; r < 4; ++r) gb[(4 * lk + r) * 17 + li] = accm[r] + accc[r] * (1.f / 2048.f);
             }
         }
+        LP_TRACE(3);
         __syncthreads();
+        LP_TRACE(4);
         // 4. cell update; the new state goes to the exchange buffer of parity s (S32 rows) and, for layer 1, to y
         if (c_thr && (c_layer == 0 ? (s < L) : (s >= 1))) {
             float pre[4];
@@ -271,6 +281,7 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
                 }
             }
         }
+        LP_TRACE(5);
         if (!DF) {
             // 5. publish: the stores are acknowledged by L2 before this workgroup arrives
             __builtin_amdgcn_s_waitcnt(0);
