@@ -27,7 +27,9 @@ static constexpr int HROW = 2 * 2048;              // staged state row: [layer 0
 static constexpr int HPITCH = HROW + 64;           // LDS row pitch (2-way instead of 16-way bank conflicts)
 static constexpr long SPIN_LIMIT = 1L << 22;
 static constexpr long SPIN_LIMIT_DF = 1L << 20;    // polls of the state itself (about a microsecond each)
-static constexpr int NLDS = 6;                      // lo-weight blocks kept in LDS instead of registers
+// lo-weight blocks kept in LDS instead of registers, and staged clip rows.  SMALL (at most 8 clips per XCD, e.g. B = 64): the
+// state tile needs 8 rows, which leaves LDS for 9 blocks per wave and registers for a double-buffered A operand
+template <bool SMALL> struct LpCfg { static constexpr int NLDS = SMALL ? 9 : 6, HROWS = SMALL ? 8 : 16; };
 
 __device__ __forceinline__ float sigm_p(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float tanh_p(float x) {
@@ -56,14 +58,15 @@ __device__ __forceinline__ _Float16 no_mark(_Float16 v) {
 #define LP_TRACE(ph) do { if (tr_on && s >= 64 && s < 72) { \
     const unsigned long long tt = __builtin_amdgcn_s_memrealtime(); \
     if (lane == 0) { a.ctl[520 + ((s - 64) * 6 + (ph)) * 2] = (unsigned)tt; a.ctl[521 + ((s - 64) * 6 + (ph)) * 2] = (unsigned)(tt >> 32); } } } while (0)
-template <bool DF>
+template <bool DF, bool SMALL>
 __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersistArgs a) {
     constexpr int NBUF = DF ? 3 : 2;
+    constexpr int NLDS = LpCfg<SMALL>::NLDS, HROWS = LpCfg<SMALL>::HROWS;
     extern __shared__ __attribute__((aligned(16))) char sm_p[];
-    char* hst = sm_p;                                                   // [16 clips][HPITCH]
-    float* gbuf = reinterpret_cast<float*>(sm_p + 16 * HPITCH);         // [3 roles][4 tiles][16 clips][17]
+    char* hst = sm_p;                                                   // [HROWS clips][HPITCH]
+    float* gbuf = reinterpret_cast<float*>(sm_p + HROWS * HPITCH);      // [3 roles][4 tiles][16 clips][17]
     // the register file holds 16 hi + 13 lo weight blocks per lane at three waves per SIMD; the last NLDS lo blocks live here
-    f32x4p* wlds = reinterpret_cast<f32x4p*>(sm_p + 16 * HPITCH + 3 * 4 * 16 * 17 * sizeof(float)) + (threadIdx.x >> 6) * NLDS * 64 + (threadIdx.x & 63);
+    f32x4p* wlds = reinterpret_cast<f32x4p*>(sm_p + HROWS * HPITCH + 3 * 4 * 16 * 17 * sizeof(float)) + (threadIdx.x >> 6) * NLDS * 64 + (threadIdx.x & 63);
     __shared__ unsigned s_xcc, s_w, s_stop;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int role = wave >> 2, ntile = wave & 3;
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
     const long gclip = c0g + c_clip;
     float cst = 0.f;
 
-    for (int e = tid; e < 16 * HPITCH / 16; e += 64 * PW) reinterpret_cast<f32x4p*>(hst)[e] = (f32x4p){0.f, 0.f, 0.f, 0.f};
+    for (int e = tid; e < HROWS * HPITCH / 16; e += 64 * PW) reinterpret_cast<f32x4p*>(hst)[e] = (f32x4p){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     const bool tr_on = (a.data_flag & 4) && xcc == 0 && w == 0 && __builtin_amdgcn_readfirstlane(wave) == 0;
     for (int s = 0; s <= L; ++s) {
@@ -229,10 +232,22 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
             if (act) {
                 const char* ap = hst + li * HPITCH + (role == 2 ? 2048 : 0) + lk * 16;
                 f32x4p accm = {0.f, 0.f, 0.f, 0.f}, accc = accm;
+                // Rows of clips this XCD does not have are zero: their lanes skip the LDS read and keep the zeros they
+                // start with (SMALL has no such rows staged at all).  The state reads of the twelve waves pace this
+                // phase, so the next block's operand is requested before this block's MFMAs are issued.
+                const bool arow = li < (SMALL ? (nb < 8 ? nb : 8) : 16);
+                f16x8p ahb[2] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}}, alb[2] = {ahb[0], ahb[0]};
+                if (arow) {
+                    ahb[0] = *reinterpret_cast<const f16x8p*>(ap);
+                    alb[0] = *reinterpret_cast<const f16x8p*>(ap + 64);
+                }
 #pragma unroll
                 for (int blk = 0; blk < 16; ++blk) {
-                    const f16x8p ah = *reinterpret_cast<const f16x8p*>(ap + blk * 128);
-                    const f16x8p al = *reinterpret_cast<const f16x8p*>(ap + blk * 128 + 64);
+                    if (blk + 1 < 16 && arow) {
+                        ahb[(blk + 1) & 1] = *reinterpret_cast<const f16x8p*>(ap + (blk + 1) * 128);
+                        alb[(blk + 1) & 1] = *reinterpret_cast<const f16x8p*>(ap + (blk + 1) * 128 + 64);
+                    }
+                    const f16x8p ah = ahb[blk & 1], al = alb[blk & 1];
                     const f16x8p wlb = blk < 16 - NLDS ? wl[blk < 16 - NLDS ? blk : 0]
                                                        : __builtin_bit_cast(f16x8p, wlds[(blk - (16 - NLDS)) * 64]);
                     accm = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[blk], accm, 0, 0, 0);
@@ -298,17 +313,25 @@ int launch_lstm_persist(const LstmPersistArgs& a, hipStream_t stream) {
     if (a.H != 512) { set_error("lstm_persist: built for hidden size 512"); return -1; }
     if (a.B < 1 || a.Bx < 1 || a.Bx > 16 || 8 * a.Bx < a.B) { set_error("lstm_persist: at most 16 clips per XCD (B <= 128)"); return -1; }
     static PerDeviceOnce attr_once;
-    constexpr size_t smem = (size_t)16 * HPITCH + (size_t)3 * 4 * 16 * 17 * sizeof(float) + (size_t)PW * NLDS * 1024;
-    static_assert(smem + 64 <= 160 * 1024, "LDS budget");
+    constexpr size_t smem_big = (size_t)16 * HPITCH + (size_t)3 * 4 * 16 * 17 * sizeof(float) + (size_t)PW * LpCfg<false>::NLDS * 1024;
+    constexpr size_t smem_small = (size_t)8 * HPITCH + (size_t)3 * 4 * 16 * 17 * sizeof(float) + (size_t)PW * LpCfg<true>::NLDS * 1024;
+    static_assert(smem_big + 64 <= 160 * 1024 && smem_small + 64 <= 160 * 1024, "LDS budget");
     if (attr_once.first()) {
-        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)smem));
-        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)smem));
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_big));
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_big));
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_small));
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_small));
     }
     // the caller has filled hx and ctl with 0xFF bytes (data-flag form) or zeros (counter form)
-    if (a.data_flag) hipLaunchKernelGGL(lstm_persist_kernel<true>, dim3(256), dim3(64 * PW), smem, stream, a);
-    else hipLaunchKernelGGL(lstm_persist_kernel<false>, dim3(256), dim3(64 * PW), smem, stream, a);
+    const bool small = a.Bx <= 8;
+    const dim3 grid(256), block(64 * PW);
+    if (a.data_flag) {
+        if (small) hipLaunchKernelGGL((lstm_persist_kernel<true, true>), grid, block, smem_small, stream, a);
+        else hipLaunchKernelGGL((lstm_persist_kernel<true, false>), grid, block, smem_big, stream, a);
+    } else {
+        if (small) hipLaunchKernelGGL((lstm_persist_kernel<false, true>), grid, block, smem_small, stream, a);
+        else hipLaunchKernelGGL((lstm_persist_kernel<false, false>), grid, block, smem_big, stream, a);
+    }
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }
