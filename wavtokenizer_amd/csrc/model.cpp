@@ -1442,7 +1442,7 @@ using namespace wt;
 extern "C" {
 
 const char* wt_last_error(void) { return g_err.c_str(); }
-const char* wt_version(void) { return "wavtokenizer_amd 0.1 (gfx950, fp32 MFMA)"; }
+const char* wt_version(void) { return "wavtokenizer_amd 0.1 (gfx950, split-f16 MFMA products, fp32 accumulation)"; }
 
 int wt_model_create(const wt_arch* arch, const wt_tensor* tensors, int32_t n_tensors, int32_t device, wt_model** out) {
     if (!arch || !tensors || !out) { set_error("wt_model_create: null argument"); return WT_ERR_INVALID; }
