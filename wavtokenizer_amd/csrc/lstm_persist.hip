@@ -229,21 +229,44 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
         //    W_hh_l1 . h1[s-2] (layer 1, t = s-1)
         {
             const bool act = role == 0 ? (s < L) : (s >= 1);
-            if (act) {
-                const char* ap = hst + li * HPITCH + (role == 2 ? 2048 : 0) + lk * 16;
+            if (act && SMALL) {
+                // At most 8 clips: the 16-row A operand holds the hi halves of the 8 clip rows in rows 0-7 and their lo
+                // halves in rows 8-15, so ONE MFMA against W_hi yields the main term (rows 0-7) and the lo.W_hi correction
+                // (rows 8-15); a second one against W_lo yields the hi.W_lo correction in rows 0-7 (its rows 8-15 are the
+                // lo.lo term nobody needs): two MFMAs per block instead of three, one 16-byte LDS read per lane per block.
+                const char* ap = hst + (li & 7) * HPITCH + (role == 2 ? 2048 : 0) + lk * 16 + ((li & 8) ? 64 : 0);
+                const bool arow = (li & 7) < nb;                   // absent clip rows stay zero and are not read
                 f32x4p accm = {0.f, 0.f, 0.f, 0.f}, accc = accm;
-                // Rows of clips this XCD does not have are zero: their lanes skip the LDS read and keep the zeros they
-                // start with (SMALL has no such rows staged at all).  The state reads of the twelve waves pace this
-                // phase, so the next block's operand is requested before this block's MFMAs are issued.
-                const bool arow = li < (SMALL ? (nb < 8 ? nb : 8) : 16);
-                f16x8p ahb[2] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}}, alb[2] = {ahb[0], ahb[0]};
-                if (arow) {
-                    ahb[0] = *reinterpret_cast<const f16x8p*>(ap);
-                    alb[0] = *reinterpret_cast<const f16x8p*>(ap + 64);
-                }
+                f16x8p a1b[2] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
+                if (arow) a1b[0] = *reinterpret_cast<const f16x8p*>(ap);
 #pragma unroll
                 for (int blk = 0; blk < 16; ++blk) {
-                    if (blk + 1 < 16 && arow) {
+                    if (blk + 1 < 16 && arow) a1b[(blk + 1) & 1] = *reinterpret_cast<const f16x8p*>(ap + (blk + 1) * 128);
+                    const f16x8p a1 = a1b[blk & 1];
+                    const f16x8p wlb = blk < 16 - NLDS ? wl[blk < 16 - NLDS ? blk : 0]
+                                                       : __builtin_bit_cast(f16x8p, wlds[(blk - (16 - NLDS)) * 64]);
+                    accm = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, wh[blk], accm, 0, 0, 0);
+                    accc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, wlb, accc, 0, 0, 0);
+                }
+                // D: col = lane & 15 (gate row), row = 4 (lane >> 4) + reg: clip r's main term sits in lanes lk < 2, its
+                // lo.W_hi correction 32 lanes further up
+                float* gb = gbuf + ((role * 4 + ntile) * 16) * 17;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float c2 = __shfl_down(accm[r], 32, 64);
+                    if (lk < 2) gb[(4 * lk + r) * 17 + li] = accm[r] + (accc[r] + c2) * (1.f / 2048.f);
+                }
+            } else if (act) {
+                const char* ap = hst + li * HPITCH + (role == 2 ? 2048 : 0) + lk * 16;
+                f32x4p accm = {0.f, 0.f, 0.f, 0.f}, accc = accm;
+                // the state reads of the twelve waves pace this phase: the next block's operand is requested before this
+                // block's MFMAs are issued
+                f16x8p ahb[2], alb[2];
+                ahb[0] = *reinterpret_cast<const f16x8p*>(ap);
+                alb[0] = *reinterpret_cast<const f16x8p*>(ap + 64);
+#pragma unroll
+                for (int blk = 0; blk < 16; ++blk) {
+                    if (blk + 1 < 16) {
                         ahb[(blk + 1) & 1] = *reinterpret_cast<const f16x8p*>(ap + (blk + 1) * 128);
                         alb[(blk + 1) & 1] = *reinterpret_cast<const f16x8p*>(ap + (blk + 1) * 128 + 64);
                     }
