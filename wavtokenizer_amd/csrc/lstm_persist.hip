@@ -28,8 +28,9 @@ static constexpr int HPITCH = HROW + 64;           // LDS row pitch (2-way inste
 static constexpr long SPIN_LIMIT = 1L << 22;
 static constexpr long SPIN_LIMIT_DF = 1L << 20;    // polls of the state itself (about a microsecond each)
 // lo-weight blocks kept in LDS instead of registers, and staged clip rows.  SMALL (at most 8 clips per XCD, e.g. B = 64): the
-// state tile needs 8 rows, which leaves LDS for 9 blocks per wave and registers for a double-buffered A operand
-template <bool SMALL> struct LpCfg { static constexpr int NLDS = SMALL ? 9 : 6, HROWS = SMALL ? 8 : 16; };
+// state tile needs 8 rows and one 4-register A operand per block (hi and lo rows packed, see the product phase), which leaves
+// room for a double-buffered operand; 7 blocks in LDS measured the same as 8 or 9
+template <bool SMALL> struct LpCfg { static constexpr int NLDS = SMALL ? 7 : 6, HROWS = SMALL ? 8 : 16; };
 
 __device__ __forceinline__ float sigm_p(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float tanh_p(float x) {
