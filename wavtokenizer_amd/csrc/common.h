@@ -100,6 +100,7 @@ struct GemmArgs {
                           // the two output frames that share an input frame read it in adjacent K steps (L2 hit, not a re-fetch)
     int stage_epi = 0;    // gemm16s: epilogue staged through per-wave LDS scratch at byte offset stage_off (set by the launcher)
     int stage_off = 0;
+    int pc_off = 0;       // gemm16s: byte offset of the per-wave bias (and gamma) cache in LDS, 0 = vectors read from global memory
     int dbg = 0;          // gemm16s timing experiments only (WT_GEMM16S_DBG): 1 no DMA in the K loop, 2 no MFMA, 4 no epilogue
 };
 

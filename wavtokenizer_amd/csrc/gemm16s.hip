@@ -152,6 +152,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(Wg), 0, (int)(w_span < 0x7fffffffL ? w_span : 0x7fffffffL), 0x00020000);
 
+    // bias / gamma cache (see the persistent loop): the vectors of the epilogues that store between their loads
+    constexpr bool PCACHE = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ELU || EPI == EPI_BIAS_RES ||
+                            EPI == EPI_BIAS_RES_ELU || EPI == EPI_BIAS_GAMMA_RES;
+    constexpr int PC_BYTES = WN * 4 * (EPI == EPI_BIAS_GAMMA_RES ? 2 : 1);
+    const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.bias ? p.bias : p.C), 0, p.bias ? p.N * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsGamma = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.gamma ? p.gamma : p.C), 0, p.gamma ? p.N * 4 : 0, 0x00020000);
+    const bool pc_on = PCACHE && p.pc_off && p.bias;
+    const char* pcw = smem_s + p.pc_off + wave * PC_BYTES;
+
     // two [taps][BM] tables of per-(tap, row) byte offsets: the tile being loaded and the one after it
     unsigned* s_rowoff = reinterpret_cast<unsigned*>(smem_s + NSTAGE * STG);
     const int tab_sz = p.taps * BM;
@@ -314,6 +325,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
         // the table of this workgroup's next output tile: the loader turns to it NSTAGE-1 steps before this tile's
         // K loop ends, i.e. after at least one of the barriers below (host: nk >= NSTAGE + 1 in persistent launches)
         build_table(vb + G, c_par ^ 1);
+        int bm, bn;
+        tile_coords(vb, bm, bn);
+        // This wave's WN bias (and gamma) values go into a private LDS cache by DMA now, a K loop ahead of their use: a
+        // global load in the epilogue would have to wait for vmcnt(0), i.e. for every store issued before it, and the
+        // epilogue would run one store round trip at a time (it did: 15 of pwconv1's 110 us).  The K loop's counted
+        // waits only ever leave the youngest DMA pieces outstanding, so the cache is complete long before it is read.
+        if (PCACHE && p.pc_off && p.bias && lane < WN / 4) {
+            const int nb4 = (bn * BN + wn * WN + 4 * lane) * 4;
+            char* pc = smem_s + p.pc_off + wave * PC_BYTES;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBias, (lds_ptr_t)pc, 16, nb4, 0, 0, 0);
+            if (EPI == EPI_BIAS_GAMMA_RES) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsGamma, (lds_ptr_t)(pc + WN * 4), 16, nb4, 0, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -332,8 +355,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
             if (!(p.dbg & 2)) mfma_block(F1);
         }
         if (p.dbg & 4) continue;
-        int bm, bn;
-        tile_coords(vb, bm, bn);
 
     // ------------------------------------------------------------------------- epilogue
     const int row_l = lane & 31, col_h = 4 * (lane >> 5);
@@ -441,7 +462,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
                         for (int g = 0; g < 4; ++g) {
                             const int n = n0 + 8 * g + col_h;
                             f32x4 v = acc4(i, j, g);
-                            if (p.bias && n < p.N && !(p.dbg & 256)) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                            if (p.bias && n < p.N && !(p.dbg & 256))
+                                v += pc_on ? *reinterpret_cast<const f32x4*>(pcw + (n - n_w) * 4) : *reinterpret_cast<const f32x4*>(p.bias + n);
                             if (EPI == EPI_BIAS_GELU && (p.dbg & 512)) {
                             } else
                             if (EPI == EPI_BIAS_ELU || (OUT == OUT_S32_DUAL_ELU && pz == 1)) {
@@ -496,7 +518,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
                         // of the row pitch, which the consumers rely on being zero)
                         if (n + 3 >= p.N) { if (n + 1 >= p.N) v.y = 0.f; if (n + 2 >= p.N) v.z = 0.f; v.w = 0.f; }
                     }
-                    else if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                    else if (p.bias) v += pc_on ? *reinterpret_cast<const f32x4*>(pcw + (n - n_w) * 4) : *reinterpret_cast<const f32x4*>(p.bias + n);
                     if (EPI == EPI_BIAS_RES) {
                         v = v + *reinterpret_cast<const f32x4*>(p.R + (long)m * p.r_rstride + n);
                     } else if (EPI == EPI_BIAS_RES_ELU) {
@@ -507,7 +529,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
                     } else if (EPI == EPI_BIAS_GELU) {
                         v = gelu_erf_s4(v);
                     } else if (EPI == EPI_BIAS_GAMMA_RES) {
-                        const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + n);
+                        const f32x4 gm = pc_on ? *reinterpret_cast<const f32x4*>(pcw + WN * 4 + (n - n_w) * 4) : *reinterpret_cast<const f32x4*>(p.gamma + n);
                         v = *reinterpret_cast<const f32x4*>(p.R + (long)m * p.r_rstride + n) + gm * v;
                     }
                     if (OUT == OUT_S32 || OUT == OUT_S32_DUAL_ELU) store_s32_x4(crow, n, v);
@@ -552,7 +574,7 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
     constexpr size_t stage_bytes = (size_t)NSTAGE * (BM + BN) * 128;
     size_t smem = stage_bytes + 2ull * a.taps * BM * sizeof(unsigned);
     constexpr size_t smem_cap = 160 * 1024;
-    constexpr size_t smem_want = stage_bytes + 2ull * 32 * BM * sizeof(unsigned) + (size_t)WMs * WNs * 4096 + 128;
+    constexpr size_t smem_want = stage_bytes + 2ull * 32 * BM * sizeof(unsigned) + (size_t)WMs * WNs * 4096 + 8192 + 256;
     constexpr size_t smem_max = smem_want < smem_cap ? smem_want : smem_cap;
     static_assert(stage_bytes + 2 * BM * sizeof(unsigned) <= smem_cap, "LDS budget");
     if (smem > smem_cap) { set_error("gemm16s: too many taps for this tile's LDS budget"); return -1; }
@@ -571,6 +593,18 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
     const char* np = getenv("WT_GEMM16S_NONPERSISTENT");
     if (G < 8 || ntiles <= G || a.K / SBK < NSTAGE + 1 || (np && np[0] == '1')) G = ntiles;
     GemmArgs b = a;
+    {   // per-wave bias (+ gamma) cache: WN floats each, filled by DMA at the top of every output tile
+        constexpr bool pcache = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ELU || EPI == EPI_BIAS_RES ||
+                                EPI == EPI_BIAS_RES_ELU || EPI == EPI_BIAS_GAMMA_RES;
+        constexpr size_t pc_bytes = (size_t)WMs * WNs * (BN / WNs) * 4 * (EPI == EPI_BIAS_GAMMA_RES ? 2 : 1);
+        const size_t off = (smem + 127) / 128 * 128;
+        const char* npc = getenv("WT_GEMM16S_NOPCACHE");
+        if (pcache && a.bias && a.N % 4 == 0 && a.K / SBK >= 2 && off + pc_bytes <= smem_cap && !(npc && npc[0] == '1') &&
+            !(EPI == EPI_BIAS_GAMMA_RES && !a.gamma)) {
+            b.pc_off = (int)off;
+            smem = off + pc_bytes;
+        }
+    }
     {   // staged epilogue: 4 KB of scratch per wave after the stages and tables, when it fits and the layout allows
         constexpr bool can_stage = ((OUT == OUT_F32 || OUT == OUT_S32_DUAL_ELU || OUT == OUT_F32_AND_S32) && EPI == EPI_BIAS) ||
                                    (OUT == OUT_S32 && (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ELU));
