@@ -160,7 +160,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
         const_cast<float*>(p.bias ? p.bias : p.C), 0, p.bias ? p.N * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsGamma = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.gamma ? p.gamma : p.C), 0, p.gamma ? p.N * 4 : 0, 0x00020000);
-    const bool pc_on = PCACHE && p.pc_off && p.bias;
     const char* pcw = smem_s + p.pc_off + wave * PC_BYTES;
 
     // two [taps][BM] tables of per-(tap, row) byte offsets: the tile being loaded and the one after it
@@ -331,10 +330,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
         // global load in the epilogue would have to wait for vmcnt(0), i.e. for every store issued before it, and the
         // epilogue would run one store round trip at a time (it did: 15 of pwconv1's 110 us).  The K loop's counted
         // waits only ever leave the youngest DMA pieces outstanding, so the cache is complete long before it is read.
-        if (PCACHE && p.pc_off && p.bias && lane < WN / 4) {
+        if (PCACHE && lane < WN / 4) {
             const int nb4 = (bn * BN + wn * WN + 4 * lane) * 4;
             char* pc = smem_s + p.pc_off + wave * PC_BYTES;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBias, (lds_ptr_t)pc, 16, nb4, 0, 0, 0);
+            if (p.bias) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBias, (lds_ptr_t)pc, 16, nb4, 0, 0, 0);
             if (EPI == EPI_BIAS_GAMMA_RES) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsGamma, (lds_ptr_t)(pc + WN * 4), 16, nb4, 0, 0, 0);
         }
 #pragma unroll
@@ -463,7 +462,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
                             const int n = n0 + 8 * g + col_h;
                             f32x4 v = acc4(i, j, g);
                             if (p.bias && n < p.N && !(p.dbg & 256))
-                                v += pc_on ? *reinterpret_cast<const f32x4*>(pcw + (n - n_w) * 4) : *reinterpret_cast<const f32x4*>(p.bias + n);
+                                v += PCACHE ? *reinterpret_cast<const f32x4*>(pcw + (n - n_w) * 4) : *reinterpret_cast<const f32x4*>(p.bias + n);
                             if (EPI == EPI_BIAS_GELU && (p.dbg & 512)) {
                             } else
                             if (EPI == EPI_BIAS_ELU || (OUT == OUT_S32_DUAL_ELU && pz == 1)) {
@@ -518,7 +517,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
                         // of the row pitch, which the consumers rely on being zero)
                         if (n + 3 >= p.N) { if (n + 1 >= p.N) v.y = 0.f; if (n + 2 >= p.N) v.z = 0.f; v.w = 0.f; }
                     }
-                    else if (p.bias) v += pc_on ? *reinterpret_cast<const f32x4*>(pcw + (n - n_w) * 4) : *reinterpret_cast<const f32x4*>(p.bias + n);
+                    else if (p.bias) v += PCACHE ? *reinterpret_cast<const f32x4*>(pcw + (n - n_w) * 4) : *reinterpret_cast<const f32x4*>(p.bias + n);
                     if (EPI == EPI_BIAS_RES) {
                         v = v + *reinterpret_cast<const f32x4*>(p.R + (long)m * p.r_rstride + n);
                     } else if (EPI == EPI_BIAS_RES_ELU) {
@@ -529,7 +528,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
                     } else if (EPI == EPI_BIAS_GELU) {
                         v = gelu_erf_s4(v);
                     } else if (EPI == EPI_BIAS_GAMMA_RES) {
-                        const f32x4 gm = pc_on ? *reinterpret_cast<const f32x4*>(pcw + WN * 4 + (n - n_w) * 4) : *reinterpret_cast<const f32x4*>(p.gamma + n);
+                        const f32x4 gm = *reinterpret_cast<const f32x4*>(pcw + WN * 4 + (n - n_w) * 4);      // EPI_BIAS_GAMMA_RES: always cached
                         v = *reinterpret_cast<const f32x4*>(p.R + (long)m * p.r_rstride + n) + gm * v;
                     }
                     if (OUT == OUT_S32 || OUT == OUT_S32_DUAL_ELU) store_s32_x4(crow, n, v);
@@ -598,9 +597,9 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
                                 EPI == EPI_BIAS_RES_ELU || EPI == EPI_BIAS_GAMMA_RES;
         constexpr size_t pc_bytes = (size_t)WMs * WNs * (BN / WNs) * 4 * (EPI == EPI_BIAS_GAMMA_RES ? 2 : 1);
         const size_t off = (smem + 127) / 128 * 128;
-        const char* npc = getenv("WT_GEMM16S_NOPCACHE");
-        if (pcache && a.bias && a.N % 4 == 0 && a.K / SBK >= 2 && off + pc_bytes <= smem_cap && !(npc && npc[0] == '1') &&
-            !(EPI == EPI_BIAS_GAMMA_RES && !a.gamma)) {
+        if (pcache && (a.bias || EPI == EPI_BIAS_GAMMA_RES)) {
+            if (off + pc_bytes > smem_cap) { set_error("gemm16s: no LDS left for the bias cache"); return -1; }
+            if (EPI == EPI_BIAS_GAMMA_RES && !a.gamma) { set_error("gemm16s: this epilogue needs gamma"); return -1; }
             b.pc_off = (int)off;
             smem = off + pc_bytes;
         }
