@@ -457,12 +457,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
 #pragma unroll
                     for (int pz = 0; pz < (DUAL ? 2 : 1); ++pz) {
                         const bool as_f32 = OUT == OUT_F32 || (OUT == OUT_F32_AND_S32 && pz == 0);
+                        // the block's four bias vectors in one LDS round trip
+                        f32x4 bq[4];
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const int n = n0 + 8 * g + col_h;
-                            f32x4 v = acc4(i, j, g);
+                            bq[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
                             if (p.bias && n < p.N && !(p.dbg & 256))
-                                v += PCACHE ? *reinterpret_cast<const f32x4*>(pcw + (n - n_w) * 4) : *reinterpret_cast<const f32x4*>(p.bias + n);
+                                bq[g] = PCACHE ? *reinterpret_cast<const f32x4*>(pcw + (n - n_w) * 4) : *reinterpret_cast<const f32x4*>(p.bias + n);
+                        }
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4 v = acc4(i, j, g) + bq[g];
                             if (EPI == EPI_BIAS_GELU && (p.dbg & 512)) {
                             } else
                             if (EPI == EPI_BIAS_ELU || (OUT == OUT_S32_DUAL_ELU && pz == 1)) {
@@ -484,15 +490,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
                         }
                         // a wave's LDS operations execute in order and the scratch is private to the wave: no barrier
                         float* dbase = pz == 0 ? Cg : p.C2 + (long)z * p.zC;
+                        // all four read-backs first (one LDS round trip per 32x32 block, not four), then the stores
+                        f32x4 q[4];
 #pragma unroll
                         for (int it = 0; it < 4; ++it) {
                             const int r = 8 * it + (lane >> 3), ch = lane & 7;
-                            f32x4 q = *reinterpret_cast<const f32x4*>(sc + r * 128 + ((ch ^ ((r >> 1) & 7)) * 16));
+                            q[it] = *reinterpret_cast<const f32x4*>(sc + r * 128 + ((ch ^ ((r >> 1) & 7)) * 16));
+                        }
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) {
+                            const int r = 8 * it + (lane >> 3), ch = lane & 7;
                             const int m = m_w + i * 32 + r;
                             const int n = n0 + 4 * ch;             // fp32 columns; S32: byte ch * 16 of the group at n0
                             if (m < p.M && (!as_f32 || n < p.N) && !(p.dbg & 128)) {
                                 float* dst = dbase + (long)m * p.c_rstride + n;
-                                *reinterpret_cast<f32x4*>(dst) = q;
+                                *reinterpret_cast<f32x4*>(dst) = q[it];
                             }
                         }
                     }
