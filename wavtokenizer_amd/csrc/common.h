@@ -96,6 +96,7 @@ struct GemmArgs {
     int*   vq_pidx = nullptr;
     int vq_nparts = 0;
     int group_m = 8;      // tile scheduling group (set by launch_gemm)
+    int group_n = 0;      // gemm16s: column tiles per scheduling block (0 = all): an XCD's share of tiles then spans fewer weight panels
     int tap_pair = 0;     // gemm16s: K slot q holds tap (q >> 1) + (q & 1) * stride (k = 2 * stride convs; weights packed alike):
                           // the two output frames that share an input frame read it in adjacent K steps (L2 hit, not a re-fetch)
     int stage_epi = 0;    // gemm16s: epilogue staged through per-wave LDS scratch at byte offset stage_off (set by the launcher)

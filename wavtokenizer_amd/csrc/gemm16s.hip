@@ -134,14 +134,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
 
     // virtual block -> (row tile, column tile): XCD-contiguous, then grouped GM row tiles at a time (gemm.hip)
     auto tile_coords = [&](int vb, int& bm, int& bn) {
-        const int tile = xcd_remap_s(vb, ntiles);
-        const int per_group = p.group_m * tiles_n;
+        int tile = xcd_remap_s(vb, ntiles);
+        // column blocks of group_n tiles (the last one may be narrower), inside a block groups of group_m row tiles
+        const int GN = p.group_n > 0 && p.group_n < tiles_n ? p.group_n : tiles_n;
+        const int blk_full = tiles_m * GN, nfull = tiles_n / GN;
+        int nblk = tile / blk_full, gn = GN;
+        if (nblk >= nfull) { nblk = nfull; gn = tiles_n - nfull * GN; }
+        tile -= nblk * blk_full;
+        const int per_group = p.group_m * gn;
         const int grp = tile / per_group;
         const int first_m = grp * p.group_m;
         const int gsz = tiles_m - first_m < p.group_m ? tiles_m - first_m : p.group_m;
         const int in_grp = tile - grp * per_group;
         bm = first_m + in_grp % gsz;
-        bn = in_grp / gsz;
+        bn = nblk * GN + in_grp / gsz;
     };
     auto first_clip = [&](int bm) { return (bm * BM < p.M ? bm * BM : p.M - 1) / p.T_out; };
 
@@ -701,6 +707,8 @@ int launch_gemm16s(const GemmArgs& a_in, int epi, int out, hipStream_t s) {
     if (c.pad_mode == PAD_REFLECT && c.Tp < c.T_in) { set_error("gemm16s: reflect Tp < T_in"); return -1; }
     GemmArgs a = a_in;
     a.group_m = (a.N + 191) / 192 > 8 ? 8 : 1;
+    if (const char* e = getenv("WT_GEMM16S_GM")) a.group_m = atoi(e) > 0 ? atoi(e) : a.group_m;      // sweeps (tools/gemm16s_bench.py)
+    if (const char* e = getenv("WT_GEMM16S_GN")) a.group_n = atoi(e);
     if ((out == OUT_S32_DUAL_ELU || out == OUT_F32_AND_S32) && !c.C2) { set_error("gemm16s: this output format needs C2"); return -1; }
     if (epi == EPI_ARGMAX && (!c.vq_xx || !c.vq_ee || !c.vq_pval || !c.vq_pidx || c.vq_nparts != gemm16s_vq_parts(c.N))) {
         set_error("gemm16s: argmax epilogue needs xx, ee and (value, index) slots for gemm16s_vq_parts(N) parts"); return -1;
