@@ -217,3 +217,24 @@ def test_packed_weights_round_trip(tmp_path):
     assert not m2.training
     for k, v in m.state_dict().items():
         assert torch.equal(m2.state_dict()[k], v), k
+
+
+def test_graph_plan_selection_is_host_logic():
+    """Which calls get a hipGraph plan (WT_PLAN_FLAG_GRAPH) is decided on the host: batches up to the limit, never with
+    debug taps (stage buffers must stay addressable), off when the limit is 0; the flag is part of the plan key."""
+    from wavtokenizer_amd import WavTokenizer, NAMED_ARCHS, _capi
+    m = WavTokenizer.from_arch(NAMED_ARCHS["hop600"])
+    assert m._graph_flags(1) & _capi.WT_PLAN_FLAG_GRAPH and m._graph_flags(16) & _capi.WT_PLAN_FLAG_GRAPH
+    assert not (m._graph_flags(17) & _capi.WT_PLAN_FLAG_GRAPH)
+    m.set_graph_max_clips(64)
+    assert m._graph_flags(64) & _capi.WT_PLAN_FLAG_GRAPH
+    m.set_graph_max_clips(0)
+    assert m._graph_flags(1) == 0
+    m.set_graph_max_clips(16)
+    m.set_debug_keep_stages(True)
+    assert m._graph_flags(1) == _capi.WT_PLAN_FLAG_KEEP_STAGES
+    m.set_debug_keep_stages(False)
+    m.set_lstm_mode("step")
+    assert m._graph_flags(2) == (_capi.WT_PLAN_FLAG_STEP_LSTM | _capi.WT_PLAN_FLAG_GRAPH)
+    assert {_capi.WT_PLAN_FLAG_KEEP_STAGES, _capi.WT_PLAN_FLAG_FP32_GEMM, _capi.WT_PLAN_FLAG_STEP_LSTM,
+            _capi.WT_PLAN_FLAG_GRAPH} == {1, 2, 4, 8}
