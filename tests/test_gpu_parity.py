@@ -528,3 +528,20 @@ def test_graph_replay_matches_direct_launches(gpu_model):
     keep = f1.clone()
     m.encode_infer(wavs[1], bandwidth_id=BW)
     assert torch.equal(f1, keep)
+
+
+def test_persistent_lstm_long_sequence(gpu_model):
+    """400 and 1200 recurrent steps (10 s / 30 s clips): the three exchange buffers of the persistent LSTM rotate hundreds
+    of times; codes must still equal the launch-per-step kernel's."""
+    name, m, sd = gpu_model
+    from wavtokenizer_amd import synth
+    hop = m.arch.hop
+    for B, L in ((5, 400), (2, 1200)):
+        wav = torch.from_numpy(synth.make_clips(B, L * hop, seed=640 + B)).cuda()
+        _f1, c1 = m.encode_infer(wav, bandwidth_id=BW)
+        m.set_lstm_mode("step")
+        try:
+            _f2, c2 = m.encode_infer(wav, bandwidth_id=BW)
+        finally:
+            m.set_lstm_mode("persistent")
+        assert c1.shape == (1, B, L) and torch.equal(c1, c2), (B, L)
