@@ -545,3 +545,17 @@ def test_persistent_lstm_long_sequence(gpu_model):
         finally:
             m.set_lstm_mode("persistent")
         assert c1.shape == (1, B, L) and torch.equal(c1, c2), (B, L)
+
+
+def test_decode_long_sequences_against_oracle(gpu_model):
+    """Sequences beyond the one-slab GroupNorm kernel (L > 256: chunk statistics merged in chunk order, attention over a
+    long window) against the oracle; 777 is not a multiple of the 128-row chunk."""
+    name, m, sd = gpu_model
+    orc = _oracle(name, sd)
+    for i, (B, L) in enumerate(((2, 300), (1, 777))):
+        feats = torch.randn(B, 512, L, generator=torch.Generator().manual_seed(4200 + i)) * 0.5
+        with torch.inference_mode():
+            want = orc.decode(feats, BW)
+        got = m.decode(feats.cuda(), bandwidth_id=BW)
+        assert tuple(got.shape) == tuple(want.shape)
+        assert rel_l2(got.cpu().numpy(), want.numpy()) < WAV_REL_TOL, (B, L)

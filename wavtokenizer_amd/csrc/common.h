@@ -122,10 +122,12 @@ int launch_conv_first(const float* wav, const float* w /*[7][Cout]*/, const floa
 int launch_conv_last(const float* x /*[B][T][Cin]*/, const float* w /*[k][Cin]*/, const float* bias, float* y /*[B][T]*/,
                      int B, long T, int Cin, int k, int elu_in, hipStream_t s);
 int launch_transpose(const float* in, float* out, int B, int R, int C, hipStream_t s, int out_s32 = 0);  // [B][R][C] -> [B][C][R]
+// `part`: gn_part_floats() floats of scratch for sequences too long for the one-slab kernel (chunk statistics)
+size_t gn_part_floats(int B, int L, int groups);
 int launch_gn_stats(const float* x, const float* gamma, const float* beta, float* scale, float* shift, int B, int L,
-                    int C, int groups, float eps, hipStream_t s);
+                    int C, int groups, float eps, hipStream_t s, float* part = nullptr);
 int launch_gn_apply(const float* x, const float* gamma, const float* beta, float* scale, float* shift, float* y,
-                    int swish, int B, int L, int C, int groups, float eps, hipStream_t s, int out_s32 = 0);
+                    int swish, int B, int L, int C, int groups, float eps, hipStream_t s, int out_s32 = 0, float* part = nullptr);
 enum RowNormMode : int { RN_DWCONV = 0, RN_PLAIN = 1, RN_AFFINE_IN = 2 };
 int launch_rownorm(int mode, const float* x, float* y, int B, int L, int C, const float* dw_w /*[7][C]*/,
                    const float* dw_b, const float* in_scale, const float* in_shift, const float* out_scale,

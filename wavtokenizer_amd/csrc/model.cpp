@@ -1111,6 +1111,7 @@ static int build_decode(wt_plan* P) {
     };
     snapshot("bb.embed");
     const int sc = P->buf("bb.gn_scale", (size_t)B * D), sh = P->buf("bb.gn_shift", (size_t)B * D);
+    const int gp = P->buf("bb.gn_part", gn_part_floats(B, L, 32));       // chunk statistics (long clips)
     const int h1 = P->buf("bb.h1", (size_t)Mrows * D);
     const int h2 = P->buf("bb.h2", (size_t)Mrows * D);
 
@@ -1118,8 +1119,8 @@ static int build_decode(wt_plan* P) {
     // kernel (a second pass over its own L x 24 slab) instead of in the conv's operand staging,
     // where every element would be re-normalised by each of the 18 (tap, column-tile) re-reads.
     auto resnet = [&](const PosRes& r, const std::string& name) {
-        P->step({x, sc, sh, h1}, [=](const RunCtx& c) {
-            return launch_gn_apply(P->ptr(c, x), r.n1w, r.n1b, P->ptr(c, sc), P->ptr(c, sh), P->ptr(c, h1), 1, B, L, D, 32, 1e-6f, c.stream, s32);
+        P->step({x, sc, sh, h1, gp}, [=](const RunCtx& c) {
+            return launch_gn_apply(P->ptr(c, x), r.n1w, r.n1b, P->ptr(c, sc), P->ptr(c, sh), P->ptr(c, h1), 1, B, L, D, 32, 1e-6f, c.stream, s32, P->ptr(c, gp));
         }, 1, "res.gn1");
         GemmArgs a1 = zconv_args(r.c1, B, L);
         P->step({h1, h2}, [=](const RunCtx& c) {
@@ -1127,8 +1128,8 @@ static int build_decode(wt_plan* P) {
             if (s32) return gemm_s32(P, a, EPI_BIAS, 0, c.stream);
             return gemm_auto(P, a, PRO_NONE, EPI_BIAS, c.stream);
         }, 1, "res.conv1");
-        P->step({h2, sc, sh, h1}, [=](const RunCtx& c) {
-            return launch_gn_apply(P->ptr(c, h2), r.n2w, r.n2b, P->ptr(c, sc), P->ptr(c, sh), P->ptr(c, h1), 1, B, L, D, 32, 1e-6f, c.stream, s32);
+        P->step({h2, sc, sh, h1, gp}, [=](const RunCtx& c) {
+            return launch_gn_apply(P->ptr(c, h2), r.n2w, r.n2b, P->ptr(c, sc), P->ptr(c, sh), P->ptr(c, h1), 1, B, L, D, 32, 1e-6f, c.stream, s32, P->ptr(c, gp));
         }, 1, "res.gn2");
         GemmArgs a2 = zconv_args(r.c2, B, L);
         P->step({h1, x}, [=](const RunCtx& c) {
@@ -1148,8 +1149,8 @@ static int build_decode(wt_plan* P) {
         const int S = P->buf("bb.attn.s", (size_t)Mrows * Lp);                // fp32 scores
         const int Ps = P->buf("bb.attn.p", (size_t)Mrows * Lp);               // S32 probabilities
         const int o = P->buf("bb.attn.o", (size_t)Mrows * D);                 // S32
-        P->step({x, sc, sh, h1}, [=](const RunCtx& c) {
-            return launch_gn_apply(P->ptr(c, x), M->at_nw, M->at_nb, P->ptr(c, sc), P->ptr(c, sh), P->ptr(c, h1), 0, B, L, D, 32, 1e-6f, c.stream, 1);
+        P->step({x, sc, sh, gp, h1}, [=](const RunCtx& c) {
+            return launch_gn_apply(P->ptr(c, x), M->at_nw, M->at_nb, P->ptr(c, sc), P->ptr(c, sh), P->ptr(c, h1), 0, B, L, D, 32, 1e-6f, c.stream, 1, P->ptr(c, gp));
         }, 1, "attn.gn");
         GemmArgs aqk = linear_args(M->at_Wqk, M->at_bqk, Mrows, 2 * D, D);
         P->step({h1, qk}, [=](const RunCtx& c) {
@@ -1191,8 +1192,8 @@ static int build_decode(wt_plan* P) {
         const int vt = P->buf("bb.attn.vt", (size_t)B * D * Lp);
         const int S = P->buf("bb.attn.s", (size_t)Mrows * Lp);
         const int o = P->buf("bb.attn.o", (size_t)Mrows * D);
-        P->step({x, sc, sh, h1}, [=](const RunCtx& c) {
-            return launch_gn_apply(P->ptr(c, x), M->at_nw, M->at_nb, P->ptr(c, sc), P->ptr(c, sh), P->ptr(c, h1), 0, B, L, D, 32, 1e-6f, c.stream);
+        P->step({x, sc, sh, gp, h1}, [=](const RunCtx& c) {
+            return launch_gn_apply(P->ptr(c, x), M->at_nw, M->at_nb, P->ptr(c, sc), P->ptr(c, sh), P->ptr(c, h1), 0, B, L, D, 32, 1e-6f, c.stream, 0, P->ptr(c, gp));
         }, 1, "attn.gn");
         GemmArgs aqk = linear_args(M->at_Wqk, M->at_bqk, Mrows, 2 * D, D);
         P->step({h1, qk}, [=](const RunCtx& c) {
@@ -1232,8 +1233,8 @@ static int build_decode(wt_plan* P) {
     resnet(M->res[3], "bb.pos_net.4");
     // pos_net[5] GroupNorm + backbone.norm AdaLayerNorm (models.py:213,228), fused into one row pass
     const int xc = P->buf(keep ? "bb.x2" : "bb.norm", (size_t)Mrows * D);
-    P->step({x, sc, sh}, [=](const RunCtx& c) {
-        return launch_gn_stats(P->ptr(c, x), M->gn5w, M->gn5b, P->ptr(c, sc), P->ptr(c, sh), B, L, D, 32, 1e-6f, c.stream);
+    P->step({x, gp, sc, sh}, [=](const RunCtx& c) {
+        return launch_gn_stats(P->ptr(c, x), M->gn5w, M->gn5b, P->ptr(c, sc), P->ptr(c, sh), B, L, D, 32, 1e-6f, c.stream, P->ptr(c, gp));
     });
     P->step({x, sc, sh, xc}, [=](const RunCtx& c) {
         return launch_rownorm(RN_AFFINE_IN, P->ptr(c, x), P->ptr(c, xc), B, L, D, nullptr, nullptr, P->ptr(c, sc),

@@ -280,8 +280,14 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     }
 }
 
+static int launch_gn_chunked(const float*, const float*, const float*, float*, float*, float*, int, int, int, int, int, int, float,
+                             hipStream_t, int, float*);
+static int gn_slab_groups(int C, int groups);
 int launch_gn_stats(const float* x, const float* gamma, const float* beta, float* scale, float* shift, int B, int L,
-                    int C, int groups, float eps, hipStream_t s) {
+                    int C, int groups, float eps, hipStream_t s, float* part) {
+    const int GBs = gn_slab_groups(C, groups), cgs = C / groups;
+    if (part && L > 256 && GBs && (cgs % 4 == 0) && (C % 4 == 0) && GBs <= 8)
+        return launch_gn_chunked(x, gamma, beta, scale, shift, nullptr, 0, B, L, C, groups, GBs, eps, s, 0, part);
     hipLaunchKernelGGL(gn_stats_kernel<0>, dim3(groups, B), dim3(256), 0, s, x, gamma, beta, scale, shift,
                        (float*)nullptr, L, C, C / groups, eps, 0);
     WT_HIP_CHECK(hipGetLastError());
@@ -396,8 +402,126 @@ __global__ __launch_bounds__(512) void gn_tile_kernel(const float* __restrict__ 
     }
 }
 
+// GroupNorm for sequences too long for one LDS slab (30 s clips: L = 1200): the L x 96-channel slab is cut into chunks of
+// GN_CH rows.  Pass 1: every (slab, chunk) workgroup pulls its chunk into LDS and leaves, per group, the chunk mean and
+// the sum of squared deviations about it.  Pass 2: every workgroup merges the chunk statistics of its groups in chunk
+// order (Chan's pairwise update: deterministic, no atomics) and normalises its own chunk straight from global memory.
+// Two coalesced reads and one write per element where gn_stats_kernel makes three strided reads.
+static constexpr int GN_CH = 128;
+__global__ __launch_bounds__(256) void gn_chunk_stats_kernel(const float* __restrict__ x, float* __restrict__ part, int L,
+                                                             int C, int cg, int GB, int groups, int nch) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];      // [rows][W]
+    const int W = GB * cg, W4 = W / 4;
+    const int c0 = blockIdx.x * W, k = blockIdx.y, b = blockIdx.z;
+    const int t0 = k * GN_CH, rows = L - t0 < GN_CH ? L - t0 : GN_CH;
+    const float* xb = x + ((long)b * L + t0) * C + c0;
+    for (int e = threadIdx.x; e < rows * W4; e += 256) {
+        const int t = e / W4, q = e - t * W4;
+        *reinterpret_cast<f32x4*>(tile + t * W + q * 4) = *reinterpret_cast<const f32x4*>(xb + (long)t * C + q * 4);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int gl = wv; gl < GB; gl += 4) {
+        const float* col = tile + gl * cg;
+        const int cg4 = cg >> 2, rp = 64 / cg4, lr = lane / cg4, lq = lane - lr * cg4;
+        float sum = 0.f;
+        if (lr < rp)
+            for (int t = lr; t < rows; t += rp) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(col + t * W + lq * 4);
+                sum += (v.x + v.y) + (v.z + v.w);
+            }
+        const float mean = wave_sum(sum) / (float)(rows * cg);
+        float sq = 0.f;
+        if (lr < rp)
+            for (int t = lr; t < rows; t += rp) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(col + t * W + lq * 4);
+                const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+                sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+        sq = wave_sum(sq);
+        if (lane == 0) {
+            float* o = part + (((long)b * groups + blockIdx.x * GB + gl) * nch + k) * 2;
+            o[0] = mean; o[1] = sq;
+        }
+    }
+}
+
+template <int APPLY>   // 0: scale/shift only; 1: y = x*scale + shift; 2: y = swish(x*scale + shift)
+__global__ __launch_bounds__(256) void gn_chunk_apply_kernel(const float* __restrict__ x, const float* __restrict__ part,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ scale, float* __restrict__ shift,
+                                                             float* __restrict__ y, int L, int C, int cg, int GB, int groups,
+                                                             int nch, float eps, int s32) {
+    __shared__ float s_mean[8], s_rstd[8], s_sc[128], s_sh[128];
+    const int W = GB * cg, W4 = W / 4;
+    const int c0 = blockIdx.x * W, k = blockIdx.y, b = blockIdx.z;
+    if (threadIdx.x < GB) {
+        const float* pp = part + ((long)b * groups + blockIdx.x * GB + threadIdx.x) * nch * 2;
+        float n = 0.f, mean = 0.f, m2 = 0.f;
+        for (int q = 0; q < nch; ++q) {
+            const int rows = L - q * GN_CH < GN_CH ? L - q * GN_CH : GN_CH;
+            const float nq = (float)(rows * cg), d = pp[2 * q] - mean, tot = n + nq;
+            mean += d * (nq / tot);
+            m2 += pp[2 * q + 1] + d * d * (n * nq / tot);
+            n = tot;
+        }
+        s_mean[threadIdx.x] = mean;
+        s_rstd[threadIdx.x] = 1.f / sqrtf(m2 / n + eps);
+    }
+    __syncthreads();
+    if (threadIdx.x < W) {
+        const int c = c0 + threadIdx.x, gl = threadIdx.x / cg;
+        const float sc = s_rstd[gl] * gamma[c], sh = beta[c] - s_mean[gl] * sc;
+        s_sc[threadIdx.x] = sc; s_sh[threadIdx.x] = sh;
+        if (k == 0) { scale[(long)b * C + c] = sc; shift[(long)b * C + c] = sh; }
+    }
+    if (APPLY == 0) return;
+    __syncthreads();
+    const int t0 = k * GN_CH, rows = L - t0 < GN_CH ? L - t0 : GN_CH;
+    const float* xb = x + ((long)b * L + t0) * C + c0;
+    float* yb = y + ((long)b * L + t0) * C;
+    for (int e = threadIdx.x; e < rows * W4; e += 256) {
+        const int t = e / W4, q = e - t * W4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long)t * C + q * 4);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(s_sc + q * 4), sh = *reinterpret_cast<const f32x4*>(s_sh + q * 4);
+        f32x4 o = v * sc + sh;
+        if (APPLY == 2) {
+            o.x *= __builtin_amdgcn_rcpf(1.f + __expf(-o.x)); o.y *= __builtin_amdgcn_rcpf(1.f + __expf(-o.y));
+            o.z *= __builtin_amdgcn_rcpf(1.f + __expf(-o.z)); o.w *= __builtin_amdgcn_rcpf(1.f + __expf(-o.w));
+        }
+        if (s32) store_s32_4(yb + (long)t * C, c0 + q * 4, o);
+        else *reinterpret_cast<f32x4*>(yb + (long)t * C + c0 + q * 4) = o;
+    }
+}
+
+size_t gn_part_floats(int B, int L, int groups) { return (size_t)B * groups * ((L + GN_CH - 1) / GN_CH) * 2; }
+
+// the chunked pair of launches; mode as gn_chunk_apply_kernel's APPLY
+static int launch_gn_chunked(const float* x, const float* gamma, const float* beta, float* scale, float* shift, float* y,
+                             int mode, int B, int L, int C, int groups, int GB, float eps, hipStream_t s, int out_s32,
+                             float* part) {
+    const int cg = C / groups, nch = (L + GN_CH - 1) / GN_CH;
+    const size_t smem = (size_t)GN_CH * GB * cg * sizeof(float);
+    static PerDeviceOnce attr_once;
+    if (attr_once.first())
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gn_chunk_stats_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    hipLaunchKernelGGL(gn_chunk_stats_kernel, dim3(groups / GB, nch, B), dim3(256), smem, s, x, part, L, C, cg, GB, groups, nch);
+    const dim3 grid(groups / GB, mode ? nch : 1, B);
+    if (mode == 0) hipLaunchKernelGGL(gn_chunk_apply_kernel<0>, grid, dim3(256), 0, s, x, part, gamma, beta, scale, shift, y, L, C, cg, GB, groups, nch, eps, out_s32);
+    else if (mode == 1) hipLaunchKernelGGL(gn_chunk_apply_kernel<1>, grid, dim3(256), 0, s, x, part, gamma, beta, scale, shift, y, L, C, cg, GB, groups, nch, eps, out_s32);
+    else hipLaunchKernelGGL(gn_chunk_apply_kernel<2>, grid, dim3(256), 0, s, x, part, gamma, beta, scale, shift, y, L, C, cg, GB, groups, nch, eps, out_s32);
+    WT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+static int gn_slab_groups(int C, int groups) {      // groups per slab: a multiple of 32 channels, at most 128
+    const int cg = C / groups;
+    for (int g = 1; g <= groups; ++g)
+        if (groups % g == 0 && (g * cg) % 32 == 0 && g * cg <= 128) return g;
+    return 0;
+}
+
 int launch_gn_apply(const float* x, const float* gamma, const float* beta, float* scale, float* shift, float* y,
-                    int swish, int B, int L, int C, int groups, float eps, hipStream_t s, int out_s32) {
+                    int swish, int B, int L, int C, int groups, float eps, hipStream_t s, int out_s32, float* part) {
     if (out_s32 && (C % 32)) { set_error("gn_apply: an S32 output needs C % 32 == 0"); return -1; }
     const int cg = C / groups;
     // slab kernel: GB groups = a multiple of 32 channels (whole S32 groups, 16-byte rows), slab within the LDS budget
@@ -419,6 +543,8 @@ int launch_gn_apply(const float* x, const float* gamma, const float* beta, float
         WT_HIP_CHECK(hipGetLastError());
         return 0;
     }
+    if (part && GB && (cg % 4 == 0) && (C % 4 == 0) && GB * cg <= 128 && GB <= 8)
+        return launch_gn_chunked(x, gamma, beta, scale, shift, y, swish ? 2 : 1, B, L, C, groups, GB, eps, s, out_s32, part);
     if (swish)
         hipLaunchKernelGGL(gn_stats_kernel<2>, dim3(groups, B), dim3(256), 0, s, x, gamma, beta, scale, shift, y, L, C,
                            C / groups, eps, out_s32);
