@@ -829,39 +829,71 @@ int launch_row_sumsq(const float* x, float* out, long rows, int D, hipStream_t s
 __global__ __launch_bounds__(256) void vq_finalize_kernel(const float* __restrict__ pval, const int* __restrict__ pidx,
                                                           int nparts, const float* __restrict__ embed,
                                                           int64_t* __restrict__ codes, float* __restrict__ feat, int L,
-                                                          int D, int cchunk, int bins) {
-    extern __shared__ int s_code[];
-    const int b = blockIdx.x;
-    for (int t = threadIdx.x; t < L; t += 256) {
+                                                          int D, int bins) {
+    // One workgroup per (clip, 32 frames).  Phase 1: 8 lanes per frame scan the frame's partial candidates (a lane takes
+    // parts q = sub, sub + 8, ... in ascending order, the eight lanes are then merged lowest-part-first, so ties keep the
+    // lowest index like the serial scan).  Phase 2: the 32 selected codebook rows are copied through LDS (coalesced 16-byte
+    // reads of each 2 KB row) and written transposed, 32 consecutive frames per channel.
+    __shared__ int s_code[32];
+    __shared__ float tile[32][257];                       // 256 channels at a time, padded against bank conflicts
+    const int b = blockIdx.y, t0 = blockIdx.x * 32;
+    const int fr = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    const int t = t0 + fr;
+    float best = -INFINITY;
+    int bi = 0x7fffffff, bq = 0x7fffffff;
+    if (t < L) {
         const long m = (long)b * L + t;
-        float best = pval[m * nparts];
-        int bi = pidx[m * nparts];
-        for (int q = 1; q < nparts; ++q) {
+        for (int q = sub; q < nparts; q += 8) {
             const float v = pval[m * nparts + q];
-            if (v > best) { best = v; bi = pidx[m * nparts + q]; }
+            if (v > best) { best = v; bi = pidx[m * nparts + q]; bq = q; }
         }
+    }
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64), oq = __shfl_xor(bq, off, 64);
+        // the serial scan keeps the FIRST part that reaches the maximum: prefer the lower part number on equal values
+        if (ov > best || (ov == best && oq < bq)) { best = ov; bi = oi; bq = oq; }
+    }
+    if (sub == 0 && t < L) {
         // a row of NaN distances (NaN audio in) selects nothing in the GEMM epilogue: index 0 then, like torch.max on
         // an all-NaN row, instead of an out-of-range gather below
         if ((unsigned)bi >= (unsigned)bins) bi = 0;
-        s_code[t] = bi;
-        if (blockIdx.y == 0) codes[m] = (int64_t)bi;
+        s_code[fr] = bi;
+        codes[(long)b * L + t] = (int64_t)bi;
     }
-    __syncthreads();
     if (feat == nullptr) return;
-    const int c0 = blockIdx.y * cchunk;
-    const int n = cchunk * L;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int c = c0 + i / L, t = i % L;
-        if (c < D) feat[((long)b * D + c) * L + t] = embed[(long)s_code[t] * D + c];
+    __syncthreads();
+    const int nfr = L - t0 < 32 ? L - t0 : 32;
+    for (int c0 = 0; c0 < D; c0 += 256) {
+        // 32 rows x 256 channels: thread -> (row = tid / 8, 32 channels as 8 x 16 bytes, all requested before any is used)
+        if (fr < nfr) {
+            const float* src = embed + (long)s_code[fr] * D + c0 + sub * 4;
+            f32x4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const f32x4*>(src + k * 32);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float* d = &tile[fr][sub * 4 + k * 32];
+                d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w;
+            }
+        }
+        __syncthreads();
+        // write: thread -> (channel = tid, 32 frames): a wave stores 64 channels x one frame run each
+        {
+            float* dst = feat + ((long)b * D + c0 + threadIdx.x) * L + t0;
+#pragma unroll 8
+            for (int k = 0; k < nfr; ++k) dst[k] = tile[k][threadIdx.x];
+        }
+        __syncthreads();
     }
 }
 
 int launch_vq_finalize(const float* pval, const int* pidx, int nparts, const float* embed, int64_t* codes,
                        float* feat_ncl, int B, int L, int D, int bins, hipStream_t s) {
-    const int cchunk = 64;
-    dim3 grid(B, feat_ncl ? (D + cchunk - 1) / cchunk : 1);
-    hipLaunchKernelGGL(vq_finalize_kernel, grid, dim3(256), (size_t)L * sizeof(int), s, pval, pidx, nparts, embed,
-                       codes, feat_ncl, L, D, cchunk, bins);
+    if (D % 256) { set_error("vq_finalize: codebook width must be a multiple of 256"); return -1; }
+    dim3 grid((L + 31) / 32, B);
+    hipLaunchKernelGGL(vq_finalize_kernel, grid, dim3(256), 0, s, pval, pidx, nparts, embed, codes, feat_ncl, L, D, bins);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }
