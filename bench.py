@@ -192,7 +192,7 @@ def main():
     drain()
     barrier()
     # time the dominant kernel with HIP events on its launch stream during the timed steps
-    dplan = model._engine.plans[(_capi.WT_PLAN_DECODE, B, L, 0)][0]
+    dplan = model._engine.plans[(_capi.WT_PLAN_DECODE, B, L, model._graph_flags(B))][0]
     _capi.check(_capi.lib.wt_plan_set_timing(dplan, b"cnx.pwconv1"), "wt_plan_set_timing")
     barrier()
     t0 = time.perf_counter()

@@ -14,7 +14,12 @@
  *     wt_plan_workspace_bytes).  Kernels are enqueued on `stream`; nothing synchronises,
  *     allocates or frees inside wt_encode / wt_decode / wt_codes_to_features.
  *   - a wt_model is immutable after creation (folded + packed weights in HBM) and may be shared
- *     by host threads; a wt_plan is immutable too; concurrent calls need distinct workspaces.
+ *     by host threads.  A wt_plan may be shared too: host calls on one plan are serialised by a
+ *     per-plan lock (they only enqueue), and calls that may be in flight on the GPU at the same
+ *     time need distinct workspaces (the call's status word lives in the workspace).
+ *   - a call that fails ON THE DEVICE (wt_status_bits) never hands out plausible data: the guard
+ *     step that ends every plan overwrites its outputs (codes = -1, floats = NaN), and the next
+ *     host call on the plan returns the matching error once, without running (see wt_plan_status).
  *   - activations inside the library are time-major [clip][frame][channel] fp32; the API
  *     tensors keep the reference's layouts (wav (B,T); features (B,512,L); codes (K,B,L) int64).
  */
@@ -34,8 +39,19 @@ typedef enum {
     WT_ERR_MISSING_TENSOR = -2,
     WT_ERR_SHAPE = -3,
     WT_ERR_HIP = -4,          /* a HIP runtime call failed */
-    WT_ERR_NOT_INITED = -5    /* codebook buffer `inited` != 1 (core_vq.py:140-151 would run k-means) */
+    WT_ERR_NOT_INITED = -5,   /* codebook buffer `inited` != 1 (core_vq.py:140-151 would run k-means) */
+    WT_ERR_RANGE = -6,        /* the PREVIOUS call on this plan met a value outside the f16 range of the split-f16 form; its
+                                 outputs were poisoned; re-plan with WT_PLAN_FLAG_FP32_GEMM and repeat both calls */
+    WT_ERR_LSTM_SYNC = -7,    /* the PREVIOUS call's persistent LSTM lost co-residency (a step barrier timed out); its outputs
+                                 were poisoned; the plan now runs the LSTM one launch per step: repeat both calls */
+    WT_ERR_INDEX = -8         /* a code outside [0, bins) (F.embedding raises IndexError: decoder/pretrained.py:236) */
 } wt_status;
+
+/* Device-side failure bits of a call (wt_plan_status). */
+enum wt_status_bits {
+    WT_STATUS_BIT_LSTM = 1,   /* persistent LSTM: a step barrier timed out */
+    WT_STATUS_BIT_RANGE = 2   /* an S32 (split-f16) producer met |v| >= 65504 */
+};
 
 /* Architecture: the YAML keys decoder/pretrained.py:81-92 (from_hparams0802) reads. */
 typedef struct {
@@ -67,11 +83,16 @@ typedef enum {
     WT_PLAN_ENCODE = 0,          /* audio (B,T)       -> features (B,512,L) + codes (1,B,L)  */
     WT_PLAN_DECODE = 1,          /* features (B,512,L) -> audio (B, L*hop)                     */
     WT_PLAN_SEANET_DECODER = 2,  /* features (B,512,L) -> audio (B,1,L*hop): encodec.decoder   */
-    WT_PLAN_HEAD = 3             /* backbone output (B,L,dim) -> audio (B, L*hop): model.head   */
+    WT_PLAN_HEAD = 3,            /* backbone output (B,L,dim) -> audio (B, L*hop): model.head   */
+    WT_PLAN_UNIT_LSTM = 4        /* unit tests: x [B][L][512] -> SLSTM(x) [B][L][512], time-major (wt_unit_run) */
 } wt_plan_kind;
 
 enum {
-    WT_PLAN_FLAG_KEEP_STAGES = 1,  /* never alias stage buffers (debug taps; bigger workspace) */
+    WT_PLAN_FLAG_KEEP_STAGES = 1,  /* never alias stage buffers and snapshot the in-place residual stream (debug taps; bigger
+                                      workspace).  The kernels are the ones the default plan launches: taps of the shipped path;
+                                      a tap may therefore hold S32-encoded and / or ELU-applied data (wt_plan_buffer_info) */
+    WT_PLAN_FLAG_UNFUSED = 16,     /* debug twin: unfused stages, raw fp32 tensors between them (first conv, three-GEMM
+                                      resblocks, consumer-side ELU); with FP32_GEMM it is the plain fp32 restatement */
     WT_PLAN_FLAG_STEP_LSTM = 4,    /* LSTM as one launch per time step instead of the persistent per-XCD kernel */
     WT_PLAN_FLAG_GRAPH = 8,        /* small batches: the second call in a row with the same buffers records the plan's
                                       launches as a hipGraph, later calls with those buffers replay it (one
@@ -104,6 +125,16 @@ int    wt_plan_num_launches(const wt_plan* p);
 int64_t wt_plan_graph_replays(const wt_plan* p);
 /* Debug taps: byte offset / element count of a named stage buffer inside the workspace. */
 int    wt_plan_find_buffer(const wt_plan* p, const char* name, size_t* offset, size_t* numel);
+/* ... and what it holds: format bit 0: the S32 split-f16 encoding (every 32 values of a row = 128 bytes
+ * [32 x f16 hi | 32 x f16 lo], value = hi + lo * 2^-11) instead of fp32; bit 1: elu() of the reference's tensor. */
+int    wt_plan_buffer_info(const wt_plan* p, const char* name, size_t* offset, size_t* numel, int32_t* format);
+/* Device-side failure bits (wt_status_bits) that calls on this plan have reported since the last clear.  The bits of
+ * a call are visible once its stream work has completed: synchronise first to learn about the call just made.
+ * clear != 0 consumes them (and switches the plan to the launch-per-step LSTM after WT_STATUS_BIT_LSTM); bits left
+ * unconsumed make the next wt_encode / wt_decode / ... on the plan return WT_ERR_LSTM_SYNC / WT_ERR_RANGE once. */
+int    wt_plan_status(const wt_plan* p, int32_t* bits, int32_t clear);
+/* 1 when every GEMM weight fits the split-f16 form; 0: all plans of this model run the fp32 MFMA chain. */
+int    wt_model_split_ok(const wt_model* m);
 int    wt_plan_buffer_name(const wt_plan* p, int32_t index, const char** name);
 
 /* Measurement hook (bench.py's roofline leg; no counterpart in the reference): HIP events are
@@ -146,11 +177,16 @@ int wt_head(const wt_plan* p, const float* x, float* wav_out, void* workspace, v
  * model.feature_extractor.encodec.decoder(features).  wav_out [B][1][L*hop]. */
 int wt_seanet_decode(const wt_plan* p, const float* features, float* wav_out, void* workspace, void* stream);
 
-/* ---- single-stage entry points (unit parity tests; same kernels the plans launch) ---------- */
+/* ---- single-stage entry points (unit parity tests) -------------------------------------------
+ * Shipped kernels (what the default plans launch): wt_linear modes 2/3, wt_conv1d_s32, wt_vq_nearest (gemm16s.hip +
+ * vq_finalize), wt_resblock (resblock16.hip), WT_PLAN_UNIT_LSTM (lstm_persist.hip / the step kernel).  fp32 twins
+ * (gemm.hip, resblock.hip: the WT_PLAN_FLAG_FP32_GEMM path): wt_sconv1d, wt_linear mode 0, wt_vq_nearest_f32,
+ * wt_resblock with fp32_chain = 1.  The S32 entry points scale each operand by a per-tensor power of two chosen on
+ * the device (the plans' producers write S32 unscaled and report |v| >= 65504 through the status word instead). */
 
 /* Replaces: SConv1d.forward with weight-normed Conv1d (encoder/modules/conv.py:195-211), time-major
  * tensors: x [B][T][Cin] -> y [B][Tout][Cout], w [Cout][k][Cin] (already folded), reflect padding,
- * optional ELU on the input (seanet.py:49,124,136).  Tout = ceil(T/stride). */
+ * optional ELU on the input (seanet.py:49,124,136).  Tout = ceil(T/stride).  fp32 MFMA chain (gemm.hip). */
 int wt_sconv1d(const float* x, const float* w, const float* bias, float* y, int32_t B, int64_t T,
                int32_t Cin, int32_t Cout, int32_t k, int32_t stride, int32_t dilation, int32_t elu_input,
                void* stream);
@@ -160,22 +196,43 @@ int wt_sconv1d(const float* x, const float* w, const float* bias, float* y, int3
  * (gemm16.hip; needs K % 32 == 0 and a workspace of 4*N*K bytes for the split weights); 2: the same arithmetic on
  * pre-split "S32" operands staged by LDS-DMA (gemm16s.hip: the plans' producers write S32 directly; here x and w
  * are split into the workspace first, 4*(M+N)*K bytes, K % 32 == 0); 3: as 2 and y is written in S32 too
- * (N % 32 == 0; every 32 outputs of a row = 128 bytes [32 x f16 hi | 32 x f16 lo], value = hi + lo * 2^-11). */
+ * (N % 32 == 0; every 32 outputs of a row = 128 bytes [32 x f16 hi | 32 x f16 lo], value = hi + lo * 2^-11).
+ * Modes 2 / 3 need 256 more bytes of workspace (per-tensor scales). */
 int wt_linear(const float* x, const float* w, const float* bias, float* y, int64_t M, int32_t N, int32_t K,
               int32_t f16x3, void* workspace, void* stream);
 
 /* Conv1d on the S32 split-f16 kernel (gemm16s.hip), time-major x [B][T][Cin] -> y [B][Tout][Cout] fp32,
  * w [Cout][k][Cin]: zero_same = 1: nn.Conv1d(k, padding=(k-1)/2) as in decoder/models.py:29-43,177 (stride 1);
- * zero_same = 0: SConv1d reflect padding (conv.py:195-211).  Cin % 32 == 0; workspace 4*(B*T*Cin + Cout*k*Cin) bytes. */
+ * zero_same = 0: SConv1d reflect padding (conv.py:195-211).  Cin % 32 == 0; workspace 4*(B*T*Cin + Cout*k*Cin) + 256 bytes. */
 int wt_conv1d_s32(const float* x, const float* w, const float* bias, float* y, int32_t B, int64_t T, int32_t Cin,
                   int32_t Cout, int32_t k, int32_t stride, int32_t zero_same, void* workspace, void* stream);
 
 /* Replaces: EuclideanCodebook.quantize (encoder/quantization/core_vq.py:175-183): x [N][D] rows,
  * embed [bins][D]; codes_out [N] int64 = argmax_j -(|x|^2 - 2 x.e_j + |e_j|^2), ties -> lowest j.
- * workspace: wt_vq_workspace_bytes(N, bins). */
-size_t wt_vq_workspace_bytes(int64_t N, int32_t bins);
+ * wt_vq_nearest: the encoder plan's kernels (distances on gemm16s.hip with the per-slab argmax epilogue, then
+ * vq_finalize; D % 32 == 0); wt_vq_nearest_f32: the fp32 MFMA chain.  workspace: wt_vq_workspace_bytes(N, D, bins). */
+size_t wt_vq_workspace_bytes(int64_t N, int32_t D, int32_t bins);
 int wt_vq_nearest(const float* x, const float* embed, int64_t N, int32_t D, int32_t bins, int64_t* codes_out,
                   void* workspace, void* stream);
+int wt_vq_nearest_f32(const float* x, const float* embed, int64_t N, int32_t D, int32_t bins, int64_t* codes_out,
+                      void* workspace, void* stream);
+
+/* Replaces: SEANetResnetBlock.forward (encoder/modules/seanet.py:62-63): y = shortcut(x) + conv1(elu(conv3(elu(x)))),
+ * one fused launch, time-major x [B][T][C] -> y [B][T][C], C = 32 or 64; folded weights w3 [C/2][3][C], w1 [C][C/2],
+ * ws [C][C].  wav != NULL (C = 32): x is not read; the tile is built from the waveform wav [B][T] through
+ * SEANetEncoder.model[0] (seanet.py:107-110; e0_w [7][32], e0_b [32]).  elu_out: y = elu(.);  out_s32: y in the S32
+ * encoding;  fp32_chain = 0: resblock16.hip (split-f16 MFMAs, the shipped kernel), 1: resblock.hip. */
+int wt_resblock(const float* x, const float* wav, const float* e0_w, const float* e0_b, const float* w3, const float* b3,
+                const float* w1, const float* b1, const float* ws, const float* bs, float* y, int32_t B, int64_t T,
+                int32_t C, int32_t elu_out, int32_t out_s32, int32_t fp32_chain, void* stream);
+
+/* Runs a WT_PLAN_UNIT_LSTM plan: x, y [B][L][512] fp32 time-major; y = SLSTM(x) (encoder/modules/lstm.py:31-39) with
+ * the encoder's LSTM weights of the plan's model. */
+int wt_unit_run(const wt_plan* p, const float* x, float* y, void* workspace, void* stream);
+
+/* After wt_codes_to_features has completed on its stream: 1 if a call since the last query met a code outside
+ * [0, bins) (the frames it touched were written as NaN), else 0; the flag is cleared. */
+int wt_model_take_bad_codes(const wt_model* m);
 
 /* ---- helpers on either side of the hot path ------------------------------------- */
 

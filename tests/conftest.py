@@ -26,3 +26,11 @@ def pytest_sessionstart(session):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """One line with the session's parity numbers (tests/parity_log.py) so that a -q log still carries them."""
+    from tests import parity_log
+    line = parity_log.dump()
+    if line:
+        terminalreporter.write_line(line)

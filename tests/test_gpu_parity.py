@@ -48,43 +48,113 @@ def test_native_library_loaded():
         assert "libwavtok_hip.so" in f.read()
 
 
-def test_b2_stage_checkpoints(gpu_model):
-    """Every stage of encode and decode against the reference's captured activations."""
+def _plan_step_names(plan):
+    import ctypes
     from wavtokenizer_amd import _capi
-    name, m, _sd = gpu_model
+    names = []
+    for i in range(_capi.lib.wt_plan_num_steps(plan)):
+        p = ctypes.c_char_p()
+        assert _capi.lib.wt_plan_step_name(plan, i, ctypes.byref(p)) == 0
+        names.append(p.value.decode())
+    return names
+
+
+# taps of the reference that never exist in HBM on the shipped path: the first conv is folded into the fused stage-1
+# resblock (its effect is checked through enc.1), pos_net.5 + AdaLayerNorm are one row pass (checked through bb.norm),
+# the head's Linear output becomes the spectrum in the GEMM epilogue (checked through the waveform)
+FUSED_AWAY = {"enc.0", "bb.pos_net.5", "head.out"}
+
+
+@pytest.mark.parametrize("variant", ["shipped", "unfused"])
+def test_b2_stage_checkpoints(gpu_model, variant):
+    """Every stage of encode and decode against the reference's activations.
+
+    shipped: the DEFAULT plan's kernels (gemm16s / resblock16 / lstm_persist ...) with WT_PLAN_FLAG_KEEP_STAGES only
+    un-aliasing their buffers; a tap may be S32-encoded and / or hold elu(x) (wt_plan_buffer_info), so the full
+    tensors are compared with the oracle's taps (which tests/test_oracle_golden.py pins bit-for-bit to the reference's
+    captured ones) and the raw ones also with the fixture's heads.
+    unfused: the debug twin (raw fp32 tensors between unfused stages) against the fixture, as in round 1."""
+    import torch.nn.functional as F
+    from wavtokenizer_amd import _capi
+    from tests import parity_log
+    name, m, sd = gpu_model
     g = load_case(name, "b2_t72000")
-    wav = torch.from_numpy(g["wav_in"]).cuda()
-    m.set_debug_keep_stages(True)
+    wav_np = g["wav_in"]
+    wav = torch.from_numpy(wav_np).cuda()
+    B, T = wav.shape
+    taps = {}
+    if variant == "shipped":
+        orc = _oracle(name, sd)
+        with torch.inference_mode():
+            fo, co = orc.encode_infer(torch.from_numpy(wav_np), BW, taps)
+            orc.decode(fo, BW, taps)
+        assert torch.equal(co, torch.from_numpy(g["codes"]))       # the oracle is the fixture's source
+    m.set_debug_keep_stages(True, unfused=(variant == "unfused"))
     try:
         feats, codes = m.encode_infer(wav, bandwidth_id=BW)
         out = m.decode(feats, bandwidth_id=BW)
         torch.cuda.synchronize()
-        B, T = wav.shape
         L = codes.shape[-1]
-        report = []
+        report, skipped = [], set()
         stages = [k.split("/")[1] for k in g.files if k.startswith("tap/") and k.endswith("/l2")]
         for st in stages:
-            shape = tuple(g[f"tap/{st}/shape"])
-            if st.startswith("enc."):
-                kind, length = _capi.WT_PLAN_ENCODE, T
-            else:
-                kind, length = _capi.WT_PLAN_DECODE, L
-            if st in ("head.out", "bb.pos_net.5"):
-                continue          # fused into the consumer (spectrum epilogue / AdaLN row pass): never in HBM
-            buf = m.debug_stage(kind, B, length, st)
+            shape = tuple(int(v) for v in g[f"tap/{st}/shape"])
+            kind, length = (_capi.WT_PLAN_ENCODE, T) if st.startswith("enc.") else (_capi.WT_PLAN_DECODE, L)
+            try:
+                buf, fmt = m.debug_stage(kind, B, length, st)
+            except Exception:
+                skipped.add(st)
+                continue
             if st == "bb.out":
-                mine = buf.view(shape).cpu().numpy()                 # (B, L, C) in both
-                ref_head, my_head = g[f"tap/{st}/head"], mine[0][:, :16]
+                mine = buf.view(shape).cpu()                              # (B, L, C) in both
+                my_head = mine[0][:, :16].numpy()
             else:
-                Bc, C, Tt = shape                                    # reference (B, C, T); ours (B, T, C)
-                mine = buf.view(Bc, Tt, C).cpu().numpy()
-                ref_head, my_head = g[f"tap/{st}/head"], mine[0, :16, :].T
-            l2 = float(np.sqrt((mine.astype(np.float64) ** 2).sum()))
-            e_head = rel_l2(my_head, ref_head)
-            e_l2 = abs(l2 - float(g[f"tap/{st}/l2"])) / float(g[f"tap/{st}/l2"])
-            report.append((st, e_head, e_l2))
-        bad = [r for r in report if r[1] > STAGE_TOL or r[2] > STAGE_TOL]
-        assert not bad, "first diverging stage: %s (head rel-L2 %.3g, |L2| rel %.3g); all: %s" % (*bad[0], report)
+                Bc, C, Tt = shape                                         # reference (B, C, T); ours (B, T, C)
+                mine = buf.view(Bc, Tt, C).permute(0, 2, 1).cpu()
+                my_head = mine[0, :, :16].numpy()
+            ref_head = torch.from_numpy(g[f"tap/{st}/head"])
+            if fmt & _capi.BUF_ELU:
+                ref_head = F.elu(ref_head)
+            e_head = rel_l2(my_head, ref_head.numpy())
+            if variant == "shipped":
+                ref = taps[st]
+                ref = F.elu(ref) if fmt & _capi.BUF_ELU else ref
+                e_full = rel_l2(mine.numpy(), ref.numpy())
+            else:
+                assert fmt == 0, (st, fmt)                                # the debug twin keeps raw fp32 tensors
+                l2 = float(np.sqrt((mine.numpy().astype(np.float64) ** 2).sum()))
+                e_full = abs(l2 - float(g[f"tap/{st}/l2"])) / float(g[f"tap/{st}/l2"])
+            report.append((st, fmt, e_head, e_full))
+        parity_log.record(f"stage_taps[{name},{variant}]", worst_tap=max(report, key=lambda r: r[3])[0],
+                          worst_rel_l2=max(r[3] for r in report), taps=len(report))
+        bad = [r for r in report if r[2] > STAGE_TOL or r[3] > STAGE_TOL]
+        assert not bad, "first diverging stage: %s (fmt %d, head rel-L2 %.3g, full %.3g); all: %s" % (*bad[0], report)
+        if variant == "shipped":
+            assert skipped == FUSED_AWAY, skipped
+            # the plan that kept its stages launches exactly the default plan's steps (plus the residual snapshots)
+            flags = m._plan_flags
+            for kind, length in ((_capi.WT_PLAN_ENCODE, T), (_capi.WT_PLAN_DECODE, L)):
+                keep_names = _plan_step_names(m._engine.plans[(kind, B, length, flags)][0])
+                m.set_debug_keep_stages(False)
+                m.set_graph_max_clips(0)
+                try:
+                    if kind == _capi.WT_PLAN_ENCODE:
+                        m.encode_infer(wav, bandwidth_id=BW)
+                    else:
+                        m.decode(feats, bandwidth_id=BW)
+                    default_names = _plan_step_names(m._engine.plans[(kind, B, length, m._plan_flags)][0])
+                finally:
+                    m.set_graph_max_clips(16)
+                    m.set_debug_keep_stages(True)
+                snap = [n for n in keep_names if n.startswith(("bb.embed", "bb.pos_net.", "bb.convnext."))]
+                core = [n for n in keep_names if n not in snap]
+                assert len(snap) == 9 or kind == _capi.WT_PLAN_ENCODE, snap
+                # keep: row pass -> "bb.x2" then a copy named "bb.norm"; default: the row pass itself is "bb.norm"
+                core = [n for i, n in enumerate(core) if not (n == "bb.norm" and i and core[i - 1] == "bb.x2")]
+                core = ["bb.norm" if n == "bb.x2" else n for n in core]
+                assert core == default_names, (core, default_names)
+        else:
+            assert skipped == {"bb.pos_net.5", "head.out"}, skipped       # fused into their consumer in every plan
     finally:
         m.set_debug_keep_stages(False)
     assert check_codes(codes.cpu().numpy(), g["codes"], g["margin"], name) == 0
@@ -104,6 +174,9 @@ def test_b2_outputs(gpu_model):
     assert rel_l2(emb.cpu().numpy(), g["emb"]) < STAGE_TOL
     assert rel_l2(bb.cpu().numpy(), g["bb_out"]) < STAGE_TOL
     err = rel_l2(out.cpu().numpy(), g["wav_out"])
+    from tests import parity_log
+    parity_log.record(f"b2_outputs[{name}]", code_flips=0, frames=int(codes.numel()), wav_rel_l2=err,
+                      emb_rel_l2=rel_l2(emb.cpu().numpy(), g["emb"]), bb_rel_l2=rel_l2(bb.cpu().numpy(), g["bb_out"]))
     assert err < WAV_REL_TOL, err
     # features are exactly the codebook rows of the codes (core_vq.py:188-190)
     sd_embed = torch.from_numpy(synth_state_dict(name)["feature_extractor.encodec.quantizer.vq.layers.0._codebook.embed"])
@@ -160,6 +233,8 @@ def test_full_batch_against_oracle_and_invariants(gpu_model):
     size-independent properties: batch invariance (a clip's result does not depend on its
     neighbours) and the encode -> codes -> decode round trip."""
     from wavtokenizer_amd import synth
+    from tests import parity_log
+    from tests.util import NEAR_TIE_MARGIN
     name, m, sd = gpu_model
     B = 64
     wav_np = synth.make_clips(B, 72000, seed=7000)
@@ -185,14 +260,22 @@ def test_full_batch_against_oracle_and_invariants(gpu_model):
     wg = m.decode(fo.cuda(), bandwidth_id=BW)
     err = rel_l2(wg.cpu().numpy(), wo.numpy())
     per_clip = max(rel_l2(wg[i].cpu().numpy(), wo[i].numpy()) for i in range(B))
-    print(f"[{name}] B=64: near-tie code flips {flips}/{codes.numel()}, waveform rel-L2 {err:.3g} (worst clip {per_clip:.3g})")
+    margin = taps["vq.margin"].numpy().reshape(-1)
+    near_ties = int((margin < NEAR_TIE_MARGIN).sum())
+    parity_log.record(f"full_batch[{name}]", code_flips=flips, frames=int(codes.numel()), near_tie_frames=near_ties,
+                      min_margin=float(margin.min()), wav_rel_l2=err, worst_clip_rel_l2=per_clip)
+    print(f"[{name}] B=64: near-tie code flips {flips}/{codes.numel()} ({near_ties} frames have a near-tie margin), "
+          f"waveform rel-L2 {err:.3g} (worst clip {per_clip:.3g})")
     assert err < WAV_REL_TOL and per_clip < WAV_REL_TOL
-    assert flips <= 4
+    # check_codes has already failed on any flip at a healthy margin: what is left can only sit on near-tie frames
+    assert flips <= near_ties
 
 
 def test_random_ragged_lengths_against_oracle(gpu_model):
     """Seeded random clip lengths (not multiples of the hop, odd batch sizes): GPU vs the oracle on this host."""
     from wavtokenizer_amd import synth
+    from tests import parity_log
+    from tests.util import NEAR_TIE_MARGIN
     name, m, sd = gpu_model
     orc = _oracle(name, sd)
     rng = np.random.default_rng(20240 + len(name))
@@ -205,10 +288,14 @@ def test_random_ragged_lengths_against_oracle(gpu_model):
             fo, co = orc.encode_infer(torch.from_numpy(wav_np), BW, taps)
             wo = orc.decode(fo, BW)
         assert tuple(codes.shape) == tuple(co.shape), (B, T)
-        check_codes(codes.cpu().numpy(), co.numpy(), taps["vq.margin"].numpy(), f"{name} B={B} T={T}")
+        flips = check_codes(codes.cpu().numpy(), co.numpy(), taps["vq.margin"].numpy(), f"{name} B={B} T={T}")
+        margin = taps["vq.margin"].numpy().reshape(-1)
+        assert flips <= int((margin < NEAR_TIE_MARGIN).sum()), (B, T, flips)
         wg = m.decode(fo.cuda(), bandwidth_id=BW)
         assert tuple(wg.shape) == tuple(wo.shape), (B, T)
-        assert rel_l2(wg.cpu().numpy(), wo.numpy()) < WAV_REL_TOL, (B, T)
+        err = rel_l2(wg.cpu().numpy(), wo.numpy())
+        parity_log.record(f"ragged[{name},B={B},T={T}]", code_flips=flips, frames=int(codes.numel()), wav_rel_l2=err)
+        assert err < WAV_REL_TOL, (B, T)
 
 
 def test_b8_fixture_codes(gpu_model):
@@ -358,32 +445,46 @@ def test_s32_decode_path_matches_the_fp32_chain(gpu_model):
     assert rel_l2(out.cpu().numpy(), out32.cpu().numpy()) < 2e-5
 
 
-def test_vq_nearest_kernel_and_ties():
-    """wt_vq_nearest vs core_vq.py:175-183 on CPU; duplicated codebook rows tie -> lowest index."""
+@pytest.mark.parametrize("kernel", ["shipped", "fp32"])
+def test_vq_nearest_kernel_and_ties(kernel):
+    """EuclideanCodebook.quantize (core_vq.py:175-183) on the encoder plan's own kernels (wt_vq_nearest: distances on
+    gemm16s.hip with the per-slab argmax epilogue EPI_ARGMAX, then vq_finalize) and on the fp32 twin.  Exactly
+    duplicated codebook rows tie: torch.max returns the lowest index, and so must every merge level of the kernel:
+    inside a lane's 4-column run, across the lane pair (columns n and n + 4), across 8-column groups and 32-column
+    MFMA tiles of a wave, across the 96-column wave slabs, across 192-column block tiles, and across the eight lanes
+    (parts q, q + 8, ...) and part order of vq_finalize."""
     from wavtokenizer_amd._capi import lib, check
     gen = torch.Generator().manual_seed(11)
     bins, D, N = 4096, 512, 1000
     embed = torch.randn(bins, D, generator=gen)
-    embed[3000] = embed[17]          # exact duplicates: the tie must resolve to 17
-    embed[4095] = embed[2048]
+    pairs = [(1, 2), (8, 12), (3, 11), (5, 37), (40, 70), (95, 96), (10, 100), (191, 192), (50, 250), (200, 968),
+             (300, 1068), (17, 3000), (2048, 4095), (385, 1153), (4000, 4090), (2100, 2101)]
+    used = set()
+    for a, b in pairs:
+        assert a < b and not ({a, b} & used)
+        used |= {a, b}
+        embed[b] = embed[a]                                # exact duplicate: the tie must resolve to a
     x = torch.randn(N, D, generator=gen) * 0.7
-    x[0] = embed[17]
-    x[1] = embed[2048]
-    x[2] = embed[4095]
+    for r, (a, b) in enumerate(pairs):
+        x[r] = embed[a]                                    # distance 0 to both copies, far from everything else
+        x[len(pairs) + r] = embed[b] * 1.0                 # the same through the other row
     e = embed.t()
     dist = -(x.pow(2).sum(1, keepdim=True) - 2 * x @ e + e.pow(2).sum(0, keepdim=True))
     want = dist.max(dim=-1).indices
     top2 = dist.topk(2, dim=-1).values
     margin = (top2[:, 0] - top2[:, 1]).numpy()
-    ws = torch.empty(lib.wt_vq_workspace_bytes(N, bins), dtype=torch.uint8, device="cuda")
-    codes = torch.empty(N, dtype=torch.int64, device="cuda")
-    check(lib.wt_vq_nearest(_ptr(x.cuda()), _ptr(embed.cuda()), N, D, bins, _ptr(codes), _ptr(ws), None), "wt_vq_nearest")
+    ws = torch.empty(lib.wt_vq_workspace_bytes(N, D, bins), dtype=torch.uint8, device="cuda")
+    codes = torch.full((N,), -7, dtype=torch.int64, device="cuda")
+    fn = lib.wt_vq_nearest if kernel == "shipped" else lib.wt_vq_nearest_f32
+    check(fn(_ptr(x.cuda()), _ptr(embed.cuda()), N, D, bins, _ptr(codes), _ptr(ws), None), "wt_vq_nearest")
     torch.cuda.synchronize()
     got = codes.cpu()
-    assert int(got[0]) == 17 and int(got[1]) == 2048 and int(got[2]) == 2048
-    # rows 0..2 have margin 0 by construction; everything else must match exactly
+    for r, (a, b) in enumerate(pairs):
+        assert int(got[r]) == a and int(got[len(pairs) + r]) == a, (kernel, a, b, int(got[r]), int(got[len(pairs) + r]))
+    # every other row has a healthy margin and must match exactly
     bad = (got != want).nonzero().flatten().tolist()
     assert all(margin[i] < 1e-3 for i in bad), bad
+    assert len(bad) <= 2 * len(pairs)
 
 
 def test_seanet_decoder():
@@ -559,3 +660,220 @@ def test_decode_long_sequences_against_oracle(gpu_model):
         got = m.decode(feats.cuda(), bandwidth_id=BW)
         assert tuple(got.shape) == tuple(want.shape)
         assert rel_l2(got.cpu().numpy(), want.numpy()) < WAV_REL_TOL, (B, L)
+
+
+# ------------------------------------------------------ shipped kernels, one at a time, against the oracle
+def _fold(sd, prefix):
+    """weight_norm fold as wt_model_create does it (fp64): w = g * v / ||v|| (conv.py:25-34); returns [Cout][k][Cin]."""
+    g = torch.from_numpy(sd[prefix + ".weight_g"]).double()
+    v = torch.from_numpy(sd[prefix + ".weight_v"]).double()
+    w = g * v / v.flatten(1).norm(dim=1).view(-1, 1, 1)
+    return w.float().permute(0, 2, 1).contiguous(), torch.from_numpy(sd[prefix + ".bias"])
+
+
+ENC = "feature_extractor.encodec.encoder.model."
+
+
+@pytest.mark.parametrize("T", [1, 2, 127, 128, 129, 18000])
+@pytest.mark.parametrize("stage,fold", [(1, True), (1, False), (4, False)])
+def test_resblock16_kernel_against_oracle(stage, fold, T):
+    """resblock16_kernel (the fused SEANetResnetBlock the encoder plan launches: C = 32 with the first conv folded into
+    the tile fill, C = 32 plain, C = 64) against oracle.resblock (seanet.py:21-63) on tile-edge lengths: one frame, one
+    tile +- 1, many tiles; fp32, S32 and elu'd outputs."""
+    import torch.nn.functional as F
+    from wavtokenizer_amd._capi import lib, check
+    from tests import parity_log
+    sd = synth_state_dict("hop600")
+    orc = _oracle("hop600", sd)
+    C = 32 if stage == 1 else 64
+    B = 3 if T < 1000 else 2
+    gen = torch.Generator().manual_seed(100 * stage + T)
+    w3, b3 = _fold(sd, ENC + f"{stage}.block.1.conv.conv")
+    w1, b1 = _fold(sd, ENC + f"{stage}.block.3.conv.conv")
+    ws, bs = _fold(sd, ENC + f"{stage}.shortcut.conv.conv")
+    if fold:
+        wav = torch.randn(B, T, generator=gen) * 0.3
+        e0w, e0b = _fold(sd, ENC + "0.conv.conv")                    # [32][7][1]
+        e0w = e0w[:, :, 0].t().contiguous()                         # [7][32]
+        with torch.inference_mode():
+            x_ref = orc.sconv1d(wav.unsqueeze(1), ENC + "0.conv.conv")
+    else:
+        x_ref = torch.randn(B, C, T, generator=gen) * 0.8
+    with torch.inference_mode():
+        want = orc.resblock(x_ref, ENC + f"{stage}")
+    dev = lambda t: t.cuda().contiguous()
+    w3d, b3d, w1d, b1d, wsd, bsd = map(dev, (w3, b3, w1.reshape(C, C // 2), b1, ws.reshape(C, C), bs))
+    worst = 0.0
+    for elu_out, out_s32 in ((0, 0), (1, 1), (0, 1)):
+        y = torch.full((B, T, C), float("nan"), device="cuda")
+        if fold:
+            wd, e0wd, e0bd = dev(wav), dev(e0w), dev(e0b)
+            check(lib.wt_resblock(None, _ptr(wd), _ptr(e0wd), _ptr(e0bd), _ptr(w3d), _ptr(b3d), _ptr(w1d), _ptr(b1d), _ptr(wsd),
+                                  _ptr(bsd), _ptr(y), B, T, C, elu_out, out_s32, 0, None), "wt_resblock")
+        else:
+            xd = dev(x_ref.permute(0, 2, 1))
+            check(lib.wt_resblock(_ptr(xd), None, None, None, _ptr(w3d), _ptr(b3d), _ptr(w1d), _ptr(b1d), _ptr(wsd), _ptr(bsd),
+                                  _ptr(y), B, T, C, elu_out, out_s32, 0, None), "wt_resblock")
+        torch.cuda.synchronize()
+        got = _decode_s32(y.view(B * T, C), B * T, C).float().view(B, T, C) if out_s32 else y
+        ref = F.elu(want) if elu_out else want
+        err = rel_l2(got.permute(0, 2, 1).cpu().numpy(), ref.numpy())
+        worst = max(worst, err)
+        assert err < 1e-5, (stage, fold, T, elu_out, out_s32, err)
+    parity_log.record(f"resblock16[stage{stage},fold={int(fold)},T={T}]", rel_l2=worst)
+
+
+@pytest.mark.parametrize("mode", ["persistent", "step"])
+def test_lstm_kernels_against_oracle(mode):
+    """SLSTM (lstm.py:31-39) alone, on the kernels the encoder plan launches (the S32 input-projection GEMM, then
+    lstm_persist_kernel or the launch-per-step kernel), against oracle.slstm: batch sizes that leave XCDs empty (1), ragged
+    (9, 100), full (64) and at the 16-clips-per-XCD limit (128); sequences of one, two and 120 steps."""
+    from tests import parity_log
+    m, sd = _model("hop600")
+    orc = _oracle("hop600", sd)
+    m.set_lstm_mode(mode)
+    worst = 0.0
+    for B in (1, 9, 64, 100, 128):
+        for L in (1, 2, 120):
+            x = torch.randn(B, 512, L, generator=torch.Generator().manual_seed(B * 1000 + L)) * 0.7
+            with torch.inference_mode():
+                want = orc.slstm(x, ENC + "13")                            # (B, 512, L)
+            got = m._run_unit_lstm(x.permute(0, 2, 1).contiguous().cuda())
+            torch.cuda.synchronize()
+            err = rel_l2(got.permute(0, 2, 1).cpu().numpy(), want.numpy())
+            worst = max(worst, err)
+            assert err < 1e-5, (mode, B, L, err)
+    parity_log.record(f"lstm[{mode}]", rel_l2=worst)
+
+
+# --------------------------------------------------------------- range of the split-f16 representation
+@pytest.mark.parametrize("scale_x,scale_w", [(1e5, 1.0), (1e6, 1e3), (1e-7, 1.0), (1.0, 1e-7), (3e-5, 2e4)])
+def test_linear_s32_operand_range(scale_x, scale_w):
+    """wt_linear modes 2 / 3 with operands far from 1: the split form's f16 hi half would overflow at 65504 and loses
+    relative precision below 6e-5, so the entry point scales each operand by a per-tensor power of two (exact) and
+    brings the accumulators back; results must stay fp32-equivalent against float64 (decoder/modules.py:52-54 is a
+    plain fp32 addmm, which has no such range limit)."""
+    from wavtokenizer_amd._capi import lib, check
+    M, N, K = 300, 96, 768
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.randn(M, K, generator=gen) * scale_x).cuda()
+    w = (torch.randn(N, K, generator=gen) / K ** 0.5 * scale_w).cuda()
+    b = (torch.randn(N, generator=gen) * scale_x * scale_w).cuda()
+    ws = torch.empty(4 * (M + N) * K + 1024, dtype=torch.uint8, device="cuda")
+    ref = x.double() @ w.double().t() + b.double()
+    for mode in (2, 3):
+        y = torch.full((M, N), float("nan"), device="cuda")
+        check(lib.wt_linear(_ptr(x), _ptr(w), _ptr(b), _ptr(y), M, N, K, mode, _ptr(ws), None), "wt_linear")
+        torch.cuda.synchronize()
+        if mode == 3 and not (6e-5 < scale_x * scale_w < 6e4):
+            continue            # an S32-encoded OUTPUT is itself limited to the f16 range: only the fp32 output is checked here
+        got = _decode_s32(y, M, N) if mode == 3 else y.double()
+        assert torch.isfinite(got).all(), (scale_x, scale_w, mode)
+        assert ((got - ref).norm() / ref.norm()).item() < 1e-6, (scale_x, scale_w, mode)
+
+
+def test_activation_beyond_f16_range_is_loud_then_falls_back(gpu_model):
+    """Features 1e5 times the usual scale overflow the f16 hi half of the first S32 producer.  The call must not hand
+    out silent garbage: its output is overwritten with NaN and the status word says WT_STATUS_BIT_RANGE; the next call
+    re-plans on fp32 GEMMs by itself and is correct; in strict mode the failing call itself is repeated."""
+    import ctypes
+    from wavtokenizer_amd import _capi, WavTokenizer, NAMED_ARCHS
+    from tests import parity_log
+    name, _m, sd = gpu_model
+    m = WavTokenizer.from_arch(NAMED_ARCHS[name])           # a fresh model: the fallback is sticky
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    m = m.eval().to("cuda")
+    orc = _oracle(name, sd)
+    feats = torch.randn(2, 512, 50, generator=torch.Generator().manual_seed(9)) * 0.5
+    big = feats * 1e5
+    with torch.inference_mode():
+        want_big = orc.decode(big, BW)
+        want = orc.decode(feats, BW)
+    assert torch.isfinite(want_big).all()                  # the reference has no such limit
+    m.set_graph_max_clips(0)
+    out = m.decode(big.cuda(), bandwidth_id=BW)
+    torch.cuda.synchronize()
+    assert torch.isnan(out).all()                          # poisoned, not plausible
+    plan = next(p for k, (p, _w) in m._engine.plans.items() if k[0] == _capi.WT_PLAN_DECODE)
+    bits = ctypes.c_int32()
+    _capi.check(_capi.lib.wt_plan_status(plan, ctypes.byref(bits), 0), "wt_plan_status")
+    assert bits.value & _capi.WT_STATUS_BIT_RANGE
+    out2 = m.decode(big.cuda(), bandwidth_id=BW)           # WT_ERR_RANGE inside -> fp32 plan -> runs
+    assert m._plan_flags & _capi.WT_PLAN_FLAG_FP32_GEMM
+    e_big = rel_l2(out2.cpu().numpy(), want_big.numpy())
+    assert e_big < WAV_REL_TOL, e_big
+    # strict mode on a second fresh model: the failing call itself comes back correct
+    m2 = WavTokenizer.from_arch(NAMED_ARCHS[name])
+    m2.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    m2 = m2.eval().to("cuda")
+    m2.set_strict_status(True)
+    e_strict = rel_l2(m2.decode(big.cuda(), bandwidth_id=BW).cpu().numpy(), want_big.numpy())
+    assert e_strict < WAV_REL_TOL, e_strict
+    # small magnitudes need no fallback: absolute floor 2^-36 of the split form, far below fp32 rounding of the sums
+    m3, _ = _model(name)
+    tiny = feats * 1e-7
+    with torch.inference_mode():
+        want_tiny = orc.decode(tiny, BW)
+    out3 = m3.decode(tiny.cuda(), bandwidth_id=BW)
+    e_tiny = rel_l2(out3.cpu().numpy(), want_tiny.numpy())
+    m3.check_status()
+    assert e_tiny < WAV_REL_TOL, e_tiny
+    e_norm = rel_l2(m3.decode(feats.cuda(), bandwidth_id=BW).cpu().numpy(), want.numpy())
+    parity_log.record(f"range[{name}]", wav_rel_l2_x1e5_fp32_fallback=e_big, wav_rel_l2_x1e5_strict=e_strict,
+                      wav_rel_l2_x1e_7=e_tiny, wav_rel_l2=e_norm)
+
+
+def test_persistent_lstm_lost_coresidency(gpu_model):
+    """A persistent LSTM launch that cannot get its 32 workgroups per XCD resident (forced here: WT_LSTM_PERSIST_FAULT=1
+    launches eight too few and shortens the spin bound) must fail loudly on the call that failed: codes = -1, features
+    NaN, status bit set; the retry runs the launch-per-step kernel and gives the step kernel's codes."""
+    import ctypes
+    import os
+    from wavtokenizer_amd import _capi, synth
+    name, m, sd = gpu_model
+    wav = torch.from_numpy(synth.make_clips(20, 7200, seed=520)).cuda()
+    m.set_lstm_mode("step")
+    try:
+        f_ref, c_ref = m.encode_infer(wav, bandwidth_id=BW)
+    finally:
+        m.set_lstm_mode("persistent")
+    # drop cached plans so that the encode plan below is fresh (persistent)
+    m._engine.drop(lambda k: k[0] == _capi.WT_PLAN_ENCODE and k[1] == 20 and not (k[3] & _capi.WT_PLAN_FLAG_STEP_LSTM))
+    os.environ["WT_LSTM_PERSIST_FAULT"] = "1"
+    try:
+        f1, c1 = m.encode_infer(wav, bandwidth_id=BW)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["WT_LSTM_PERSIST_FAULT"]
+    assert int(c1.max()) == -1 and int(c1.min()) == -1, "a failed call must not hand out plausible codes"
+    assert torch.isnan(f1).all()
+    plan = m._engine.plans[(_capi.WT_PLAN_ENCODE, 20, 7200, m._graph_flags(20))][0]
+    bits = ctypes.c_int32()
+    _capi.check(_capi.lib.wt_plan_status(plan, ctypes.byref(bits), 0), "wt_plan_status")
+    assert bits.value & _capi.WT_STATUS_BIT_LSTM
+    f2, c2 = m.encode_infer(wav, bandwidth_id=BW)          # WT_ERR_LSTM_SYNC inside -> step kernel -> runs
+    assert torch.equal(c2, c_ref) and torch.equal(f2, f_ref)
+    # strict mode repeats the failing call itself
+    m._engine.drop(lambda k: k[0] == _capi.WT_PLAN_ENCODE)
+    m.set_strict_status(True)
+    os.environ["WT_LSTM_PERSIST_FAULT"] = "1"
+    try:
+        f3, c3 = m.encode_infer(wav, bandwidth_id=BW)
+    finally:
+        del os.environ["WT_LSTM_PERSIST_FAULT"]
+        m.set_strict_status(False)
+        m._engine.drop(lambda k: k[0] == _capi.WT_PLAN_ENCODE)
+    assert torch.equal(c3, c_ref) and torch.equal(f3, f_ref)
+
+
+def test_codes_out_of_range_raise_like_embedding(gpu_model):
+    """F.embedding raises IndexError on a code outside the codebook (decoder/pretrained.py:236); so does the drop-in."""
+    name, m, _sd = gpu_model
+    codes = torch.zeros(1, 2, 7, dtype=torch.int64, device="cuda")
+    m.codes_to_features(codes)
+    for bad in (4096, -1, 1 << 40):
+        c = codes.clone()
+        c[0, 1, 3] = bad
+        with pytest.raises(IndexError):
+            m.codes_to_features(c)
+    assert torch.isfinite(m.codes_to_features(codes)).all()      # the flag does not stick

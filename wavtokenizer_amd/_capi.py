@@ -17,18 +17,23 @@ LIB_PATH = os.environ.get("WAVTOK_HIP_LIB") or os.path.join(_HERE, "libwavtok_hi
 EXPORTS = [
     "wt_last_error", "wt_version", "wt_model_create", "wt_model_destroy", "wt_model_hop", "wt_model_weight_bytes",
     "wt_plan_create", "wt_plan_destroy", "wt_plan_workspace_bytes", "wt_plan_frames", "wt_plan_num_launches", "wt_plan_graph_replays",
-    "wt_plan_find_buffer", "wt_plan_buffer_name", "wt_plan_num_steps", "wt_plan_step_name", "wt_plan_set_timing",
-    "wt_plan_read_timing", "wt_encode", "wt_codes_to_features", "wt_decode",
-    "wt_seanet_decode", "wt_head", "wt_sconv1d", "wt_linear", "wt_conv1d_s32", "wt_vq_workspace_bytes", "wt_vq_nearest",
+    "wt_plan_find_buffer", "wt_plan_buffer_info", "wt_plan_buffer_name", "wt_plan_status", "wt_plan_num_steps", "wt_plan_step_name",
+    "wt_plan_set_timing", "wt_plan_read_timing", "wt_model_split_ok", "wt_model_take_bad_codes", "wt_encode", "wt_codes_to_features",
+    "wt_decode", "wt_seanet_decode", "wt_head", "wt_unit_run", "wt_sconv1d", "wt_linear", "wt_conv1d_s32", "wt_vq_workspace_bytes",
+    "wt_vq_nearest", "wt_vq_nearest_f32", "wt_resblock",
     "wt_resampler_create", "wt_resampler_destroy", "wt_resampler_out_length", "wt_convert_audio", "wt_pcm16",
     "wt_linear_overlap_add",
 ]
 
-WT_PLAN_ENCODE, WT_PLAN_DECODE, WT_PLAN_SEANET_DECODER, WT_PLAN_HEAD = 0, 1, 2, 3
+WT_PLAN_ENCODE, WT_PLAN_DECODE, WT_PLAN_SEANET_DECODER, WT_PLAN_HEAD, WT_PLAN_UNIT_LSTM = 0, 1, 2, 3, 4
 WT_PLAN_FLAG_KEEP_STAGES = 1
 WT_PLAN_FLAG_FP32_GEMM = 2
 WT_PLAN_FLAG_STEP_LSTM = 4
 WT_PLAN_FLAG_GRAPH = 8
+WT_PLAN_FLAG_UNFUSED = 16
+WT_ERR_RANGE, WT_ERR_LSTM_SYNC, WT_ERR_INDEX = -6, -7, -8
+WT_STATUS_BIT_LSTM, WT_STATUS_BIT_RANGE = 1, 2
+BUF_S32, BUF_ELU = 1, 2
 
 
 class WtArch(ctypes.Structure):
@@ -43,7 +48,9 @@ class WtTensor(ctypes.Structure):
 
 
 class WavTokError(RuntimeError):
-    pass
+    def __init__(self, msg, status=0):
+        super().__init__(msg)
+        self.status = status
 
 
 def _load() -> ctypes.CDLL:
@@ -71,6 +78,11 @@ def _load() -> ctypes.CDLL:
     lib.wt_plan_graph_replays.argtypes = [c_void_p]
     lib.wt_plan_graph_replays.restype = c_int64
     lib.wt_plan_find_buffer.argtypes = [c_void_p, c_char_p, POINTER(c_size_t), POINTER(c_size_t)]
+    lib.wt_plan_buffer_info.argtypes = [c_void_p, c_char_p, POINTER(c_size_t), POINTER(c_size_t), POINTER(c_int32)]
+    lib.wt_plan_status.argtypes = [c_void_p, POINTER(c_int32), c_int32]
+    lib.wt_model_split_ok.argtypes = [c_void_p]
+    lib.wt_model_take_bad_codes.argtypes = [c_void_p]
+    lib.wt_unit_run.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.wt_plan_buffer_name.argtypes = [c_void_p, c_int32, POINTER(c_char_p)]
     lib.wt_plan_num_steps.argtypes = [c_void_p]
     lib.wt_plan_step_name.argtypes = [c_void_p, c_int32, POINTER(c_char_p)]
@@ -86,9 +98,11 @@ def _load() -> ctypes.CDLL:
     lib.wt_linear.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p]
     lib.wt_conv1d_s32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32,
                                   c_int32, c_int32, c_void_p, c_void_p]
-    lib.wt_vq_workspace_bytes.argtypes = [c_int64, c_int32]
+    lib.wt_vq_workspace_bytes.argtypes = [c_int64, c_int32, c_int32]
     lib.wt_vq_workspace_bytes.restype = c_size_t
     lib.wt_vq_nearest.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
+    lib.wt_vq_nearest_f32.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
+    lib.wt_resblock.argtypes = [c_void_p] * 11 + [c_int32, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]
     lib.wt_resampler_create.argtypes = [c_int32, c_int32, c_int32, POINTER(c_void_p)]
     lib.wt_resampler_destroy.argtypes = [c_void_p]
     lib.wt_resampler_destroy.restype = None
@@ -106,4 +120,4 @@ lib = _load()
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = lib.wt_last_error()
-        raise WavTokError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")
+        raise WavTokError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}", rc)

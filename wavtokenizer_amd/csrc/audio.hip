@@ -157,10 +157,11 @@ int wt_convert_audio(const wt_resampler* r, const float* wav, int32_t B, int32_t
     const int64_t Tout = wt_resampler_out_length(r, T);
     const size_t smem = (size_t)(256 / r->nw + 2) * r->orig * sizeof(float) + (size_t)r->K * sizeof(float);
     static PerDeviceOnce attr_once;
-    if (attr_once.first()) {
+    if (int rc = attr_once.run([&]() -> int {
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(resample_mono_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    }
+        return 0;
+    })) return rc;
     dim3 grid((unsigned)((Tout + 255) / 256), B);
     hipLaunchKernelGGL(resample_mono_kernel, grid, dim3(256), smem, static_cast<hipStream_t>(stream), wav, r->kern, out, C,
                        (long)T, (long)Tout, r->orig, r->nw, r->K, r->width);

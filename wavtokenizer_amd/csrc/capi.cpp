@@ -1,0 +1,470 @@
+// The extern "C" entry points declared in include/wavtokenizer_amd.h.
+#include "model.h"
+
+namespace wt {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+thread_local LaunchCtx g_launch;
+}  // namespace wt
+
+// ================================================================================== C ABI
+using namespace wt;
+
+extern "C" {
+
+const char* wt_last_error(void) { return g_err.c_str(); }
+const char* wt_version(void) { return "wavtokenizer_amd 0.1 (gfx950, split-f16 MFMA products, fp32 accumulation)"; }
+
+int wt_model_create(const wt_arch* arch, const wt_tensor* tensors, int32_t n_tensors, int32_t device, wt_model** out) {
+    if (!arch || !tensors || !out) { set_error("wt_model_create: null argument"); return WT_ERR_INVALID; }
+    if (arch->n_ratios < 1 || arch->n_ratios > 8) { set_error("n_ratios out of range"); return WT_ERR_INVALID; }
+    if (!arch->padding_same) { set_error("only ISTFT padding='same' is implemented (the mode every reference YAML selects)"); return WT_ERR_INVALID; }
+    if (arch->num_quantizers != 1) { set_error("only num_quantizers=1 is implemented (vq.py:137 forces n_q=1 at inference)"); return WT_ERR_INVALID; }
+    if (arch->input_channels != 512) { set_error("input_channels must be 512 (SEANet dimension)"); return WT_ERR_INVALID; }
+    if (arch->dim % 256 || arch->intermediate_dim % 32) { set_error("dim must be a multiple of 256, intermediate_dim of 32"); return WT_ERR_INVALID; }
+    if (arch->dim % 32 || (arch->dim / 32) % 4) { set_error("dim/32 (GroupNorm group width) must be a multiple of 4"); return WT_ERR_INVALID; }
+    DeviceGuard dg(device);
+    if (!dg.ok) { set_error("wt_model_create: hipSetDevice failed"); return WT_ERR_HIP; }
+    std::unique_ptr<wt_model> M(new wt_model());
+    M->arch = *arch;
+    M->device = device;
+    M->hop = 1;
+    for (int i = 0; i < arch->n_ratios; ++i) M->hop *= arch->ratios[i];
+    for (int i = arch->n_ratios - 1; i >= 0; --i) M->enc_ratios.push_back(arch->ratios[i]);   // seanet.py:100
+    TensorMap tm;
+    for (int i = 0; i < n_tensors; ++i) tm.m[tensors[i].name] = {tensors[i].data, tensors[i].numel};
+    int rc = build_model(M.get(), tm);
+    if (!rc) rc = build_splits(M.get());
+    if (!rc) {
+        void* hp = nullptr;
+        void* dp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+            if (hp) (void)hipHostFree(hp);
+            set_error("wt_model_create: no host-mapped memory for the status word");
+            rc = WT_ERR_HIP;
+        } else {
+            M->bad_codes_host = static_cast<unsigned*>(hp);
+            M->bad_codes_dev = static_cast<unsigned*>(dp);
+            *M->bad_codes_host = 0;
+        }
+    }
+    if (rc) {
+        if (rc == WT_ERR_MISSING_TENSOR) set_error("state_dict tensor missing or mis-shaped: " + tm.missing);
+        for (void* p : M->allocs) (void)hipFree(p);
+        return rc;
+    }
+    *out = M.release();
+    return WT_OK;
+}
+
+void wt_model_destroy(wt_model* m) {
+    if (!m) return;
+    DeviceGuard dg(m->device);
+    for (void* p : m->allocs) (void)hipFree(p);
+    if (m->bad_codes_host) (void)hipHostFree(m->bad_codes_host);
+    delete m;
+}
+int wt_model_split_ok(const wt_model* m) { return m && m->s32_ok ? 1 : 0; }
+int wt_model_take_bad_codes(const wt_model* m) {
+    if (!m || !m->bad_codes_host) return 0;
+    const unsigned v = __atomic_exchange_n(m->bad_codes_host, 0u, __ATOMIC_RELAXED);
+    return v ? 1 : 0;
+}
+int wt_model_hop(const wt_model* m) { return m ? m->hop : 0; }
+int64_t wt_model_weight_bytes(const wt_model* m) { return m ? m->weight_bytes : 0; }
+
+int wt_plan_create(const wt_model* m, int32_t kind, int32_t B, int64_t len, int32_t flags, wt_plan** out) {
+    if (!m || !out) { set_error("wt_plan_create: null argument"); return WT_ERR_INVALID; }
+    if (B < 1 || len < 1) { set_error("wt_plan_create: B and len must be >= 1"); return WT_ERR_INVALID; }
+    if ((len + (kind == WT_PLAN_ENCODE ? m->hop - 1 : 0)) / (kind == WT_PLAN_ENCODE ? m->hop : 1) > 12000) {
+        set_error("clips longer than 12000 frames are not supported by one plan; split the clip"); return WT_ERR_INVALID;
+    }
+    DeviceGuard dg(m->device);
+    if (!dg.ok) { set_error("wt_plan_create: hipSetDevice failed"); return WT_ERR_HIP; }
+    std::unique_ptr<wt_plan> P(new wt_plan());
+    P->model = m; P->kind = kind; P->B = B; P->len = len; P->flags = flags;
+    {
+        void* hp = nullptr;
+        void* dp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+            if (hp) (void)hipHostFree(hp);
+            set_error("wt_plan_create: no host-mapped memory for the status word"); return WT_ERR_HIP;
+        }
+        P->status_host = static_cast<unsigned*>(hp);
+        P->status_dev = static_cast<unsigned*>(dp);
+        *P->status_host = 0;
+    }
+    plan_begin(P.get());
+    int rc;
+    if (kind == WT_PLAN_ENCODE) {
+        P->T = len;
+        P->L = (len + m->hop - 1) / m->hop;
+        if ((long)B * len >= (long)INT_MAX) { set_error("batch too large for one plan (32-bit row index)"); return WT_ERR_INVALID; }
+        rc = build_encode(P.get());
+    } else if (kind == WT_PLAN_DECODE) {
+        P->L = len; P->T = len * m->hop;
+        rc = build_decode(P.get());
+    } else if (kind == WT_PLAN_SEANET_DECODER) {
+        P->L = len; P->T = len * m->hop;
+        rc = build_seanet_decoder(P.get());
+    } else if (kind == WT_PLAN_HEAD) {
+        P->L = len; P->T = len * m->hop;
+        rc = build_head(P.get());
+    } else if (kind == WT_PLAN_UNIT_LSTM) {
+        P->L = len; P->T = len * m->hop;
+        rc = build_unit_lstm(P.get());
+    } else {
+        set_error("unknown plan kind"); rc = WT_ERR_INVALID;
+    }
+    if (rc) { (void)hipHostFree(P->status_host); return rc; }
+    plan_end(P.get());
+    P->layout();
+    *out = P.release();
+    return WT_OK;
+}
+void wt_plan_destroy(wt_plan* p) {
+    if (!p) return;
+    if (p->status_host) (void)hipHostFree(p->status_host);
+    if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
+    if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
+    for (auto& ev : p->ev_pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto& ev : p->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    delete p;
+}
+size_t wt_plan_workspace_bytes(const wt_plan* p) { return p ? p->ws_bytes : 0; }
+int64_t wt_plan_frames(const wt_plan* p) { return p ? p->L : 0; }
+int wt_plan_num_launches(const wt_plan* p) { return p ? p->n_launches : 0; }
+
+int wt_plan_find_buffer(const wt_plan* p, const char* name, size_t* offset, size_t* numel) {
+    if (!p || !name) return WT_ERR_INVALID;
+    for (const BufSpec& b : p->bufs)
+        if (b.name == name) {
+            if (offset) *offset = b.off;
+            if (numel) *numel = b.numel;
+            return WT_OK;
+        }
+    set_error(std::string("no stage buffer named ") + name);
+    return WT_ERR_INVALID;
+}
+int wt_plan_buffer_info(const wt_plan* p, const char* name, size_t* offset, size_t* numel, int32_t* format) {
+    if (!p || !name) return WT_ERR_INVALID;
+    for (const BufSpec& b : p->bufs)
+        if (b.name == name) {
+            if (offset) *offset = b.off;
+            if (numel) *numel = b.numel;
+            if (format) *format = b.fmt;
+            return WT_OK;
+        }
+    set_error(std::string("no stage buffer named ") + name);
+    return WT_ERR_INVALID;
+}
+int wt_plan_buffer_name(const wt_plan* p, int32_t index, const char** name) {
+    if (!p || index < 0 || index >= (int)p->bufs.size()) return WT_ERR_INVALID;
+    *name = p->bufs[index].name.c_str();
+    return WT_OK;
+}
+
+// Consumes the failure bits that earlier calls on the plan left in its host-visible word (the plan's lock is held).
+// After a lost-co-residency report the plan runs the LSTM one launch per step from now on, and a recorded graph (it
+// holds the persistent launch) is dropped.
+static unsigned consume_status(const wt_plan* p) {
+    if (!p->status_host) return 0;
+    const unsigned bits = __atomic_exchange_n(p->status_host, 0u, __ATOMIC_ACQUIRE);
+    if ((bits & WT_STATUS_LSTM) && p->persist_ok) {
+        p->persist_ok = false;
+        if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+        p->last_key = wt_plan::GraphKey{};
+    }
+    return bits;
+}
+
+static int run_plan_locked(const wt_plan* p, const RunCtx& c);
+static int run_plan(const wt_plan* p, const RunCtx& c) {
+    std::lock_guard<std::mutex> lock(p->mu);
+    DeviceGuard dg(p->model->device);
+    if (!dg.ok) { set_error("hipSetDevice failed"); return WT_ERR_HIP; }
+    if (const unsigned bits = consume_status(p)) {
+        if (bits & WT_STATUS_LSTM) {
+            set_error("an earlier persistent LSTM launch on this plan lost co-residency (a step barrier timed out); that call's "
+                      "outputs were overwritten (codes = -1, NaN); the plan now runs the LSTM one launch per step: repeat the call");
+            return WT_ERR_LSTM_SYNC;
+        }
+        set_error("an earlier call on this plan met a value outside the f16 range of the split-f16 (S32) form (|v| >= 65504); "
+                  "that call's outputs were overwritten (codes = -1, NaN); re-plan with WT_PLAN_FLAG_FP32_GEMM and repeat the call");
+        return WT_ERR_RANGE;
+    }
+    struct CtxScope {        // the launch functions take the status word from this thread's context while the steps run
+        explicit CtxScope(unsigned* s) { g_launch.status = s; }
+        ~CtxScope() { g_launch.status = nullptr; }
+    } scope(reinterpret_cast<unsigned*>(c.ws + p->bufs[p->ctl].off));
+    return run_plan_locked(p, c);
+}
+
+static int run_plan_locked(const wt_plan* p, const RunCtx& c) {
+    const bool timing = !p->timing_filter.empty();
+    if ((p->flags & WT_PLAN_FLAG_GRAPH) && !timing && !p->graph_failed) {
+        const wt_plan::GraphKey key{c.ws, c.in_f, c.out_f, c.codes, c.aux, c.bw_id};
+        if (p->graph_exec && key == p->graph_key) {
+            WT_HIP_CHECK(hipGraphLaunch(p->graph_exec, c.stream));
+            ++p->graph_replays;
+            return WT_OK;
+        }
+        if (key == p->last_key) {
+            // second call in a row with these buffers (the first ran eagerly: every one-time kernel attribute is
+            // set): record the launches on a capture stream, then replay them on the caller's stream
+            if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+            if (!p->cap_stream) WT_HIP_CHECK(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
+            RunCtx cc = c;
+            cc.stream = p->cap_stream;
+            WT_HIP_CHECK(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeRelaxed));
+            int rc = WT_OK;
+            for (size_t i = 0; i < p->steps.size() && !rc; ++i) rc = p->steps[i](cc);
+            hipGraph_t g = nullptr;
+            const hipError_t ce = hipStreamEndCapture(p->cap_stream, &g);
+            if (rc || ce != hipSuccess || !g) {
+                if (g) (void)hipGraphDestroy(g);
+                (void)hipGetLastError();
+                p->graph_failed = true;             // this plan stays on direct launches
+                if (rc) return rc;
+            } else {
+                const hipError_t ie = hipGraphInstantiate(&p->graph_exec, g, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(g);
+                if (ie != hipSuccess) { p->graph_exec = nullptr; p->graph_failed = true; (void)hipGetLastError(); }
+                else {
+                    p->graph_key = key;
+                    WT_HIP_CHECK(hipGraphLaunch(p->graph_exec, c.stream));
+                    ++p->graph_replays;
+                    return WT_OK;
+                }
+            }
+        }
+        p->last_key = key;
+    }
+    for (size_t i = 0; i < p->steps.size(); ++i) {
+        const bool timed = timing && p->step_names[i].find(p->timing_filter) != std::string::npos;
+        std::pair<hipEvent_t, hipEvent_t> ev;
+        if (timed) {
+            if (!p->ev_free.empty()) { ev = p->ev_free.back(); p->ev_free.pop_back(); }
+            else { WT_HIP_CHECK(hipEventCreate(&ev.first)); WT_HIP_CHECK(hipEventCreate(&ev.second)); }
+            WT_HIP_CHECK(hipEventRecord(ev.first, c.stream));
+        }
+        if (int rc = p->steps[i](c)) return rc;
+        if (timed) {
+            WT_HIP_CHECK(hipEventRecord(ev.second, c.stream));
+            p->ev_pending.push_back(ev);
+        }
+    }
+    return WT_OK;
+}
+
+int wt_plan_status(const wt_plan* p, int32_t* bits, int32_t clear) {
+    if (!p) return WT_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(p->mu);
+    unsigned b;
+    if (clear) {
+        DeviceGuard dg(p->model->device);
+        b = consume_status(p);
+    } else {
+        b = p->status_host ? __atomic_load_n(p->status_host, __ATOMIC_ACQUIRE) : 0u;
+    }
+    if (bits) *bits = (int32_t)b;
+    return WT_OK;
+}
+
+int64_t wt_plan_graph_replays(const wt_plan* p) { return p ? p->graph_replays : 0; }
+int wt_plan_num_steps(const wt_plan* p) { return p ? (int)p->steps.size() : 0; }
+int wt_plan_step_name(const wt_plan* p, int32_t index, const char** name) {
+    if (!p || index < 0 || index >= (int)p->step_names.size()) return WT_ERR_INVALID;
+    *name = p->step_names[index].c_str();
+    return WT_OK;
+}
+int wt_plan_set_timing(const wt_plan* p, const char* name_substr) {
+    if (!p) return WT_ERR_INVALID;
+    p->timing_filter = name_substr ? name_substr : "";
+    return WT_OK;
+}
+int wt_plan_read_timing(const wt_plan* p, double* total_ms, int64_t* launches, int32_t reset) {
+    if (!p) return WT_ERR_INVALID;
+    for (auto& ev : p->ev_pending) {
+        WT_HIP_CHECK(hipEventSynchronize(ev.second));
+        float ms = 0.f;
+        WT_HIP_CHECK(hipEventElapsedTime(&ms, ev.first, ev.second));
+        p->timing_ms += ms;
+        p->timing_n += 1;
+        p->ev_free.push_back(ev);
+    }
+    p->ev_pending.clear();
+    if (total_ms) *total_ms = p->timing_ms;
+    if (launches) *launches = p->timing_n;
+    if (reset) { p->timing_ms = 0.0; p->timing_n = 0; }
+    return WT_OK;
+}
+
+int wt_encode(const wt_plan* p, const float* wav, float* features, int64_t* codes, float* emb_out, void* workspace,
+              void* stream) {
+    if (!p || p->kind != WT_PLAN_ENCODE) { set_error("wt_encode: not an encode plan"); return WT_ERR_INVALID; }
+    if (!wav || !codes || !workspace) { set_error("wt_encode: null buffer"); return WT_ERR_INVALID; }
+    RunCtx c{static_cast<char*>(workspace), static_cast<hipStream_t>(stream), wav, features, codes, emb_out, 0};
+    return run_plan(p, c);
+}
+
+int wt_decode(const wt_plan* p, const float* features, int32_t bandwidth_id, float* wav_out, float* backbone_out,
+              void* workspace, void* stream) {
+    if (!p || p->kind != WT_PLAN_DECODE) { set_error("wt_decode: not a decode plan"); return WT_ERR_INVALID; }
+    if (!features || !wav_out || !workspace) { set_error("wt_decode: null buffer"); return WT_ERR_INVALID; }
+    if (bandwidth_id < 0 || bandwidth_id >= p->model->arch.adanorm_num_embeddings) {
+        set_error("wt_decode: bandwidth_id out of range"); return WT_ERR_INVALID;
+    }
+    RunCtx c{static_cast<char*>(workspace), static_cast<hipStream_t>(stream), features, wav_out, nullptr, backbone_out, bandwidth_id};
+    return run_plan(p, c);
+}
+
+int wt_head(const wt_plan* p, const float* x, float* wav_out, void* workspace, void* stream) {
+    if (!p || p->kind != WT_PLAN_HEAD) { set_error("wt_head: wrong plan kind"); return WT_ERR_INVALID; }
+    if (!x || !wav_out || !workspace) { set_error("wt_head: null buffer"); return WT_ERR_INVALID; }
+    RunCtx c{static_cast<char*>(workspace), static_cast<hipStream_t>(stream), x, wav_out, nullptr, nullptr, 0};
+    return run_plan(p, c);
+}
+
+int wt_seanet_decode(const wt_plan* p, const float* features, float* wav_out, void* workspace, void* stream) {
+    if (!p || p->kind != WT_PLAN_SEANET_DECODER) { set_error("wt_seanet_decode: wrong plan kind"); return WT_ERR_INVALID; }
+    if (!features || !wav_out || !workspace) { set_error("wt_seanet_decode: null buffer"); return WT_ERR_INVALID; }
+    RunCtx c{static_cast<char*>(workspace), static_cast<hipStream_t>(stream), features, wav_out, nullptr, nullptr, 0};
+    return run_plan(p, c);
+}
+
+int wt_unit_run(const wt_plan* p, const float* x, float* y, void* workspace, void* stream) {
+    if (!p || p->kind != WT_PLAN_UNIT_LSTM) { set_error("wt_unit_run: wrong plan kind"); return WT_ERR_INVALID; }
+    if (!x || !y || !workspace) { set_error("wt_unit_run: null buffer"); return WT_ERR_INVALID; }
+    RunCtx c{static_cast<char*>(workspace), static_cast<hipStream_t>(stream), x, y, nullptr, nullptr, 0};
+    return run_plan(p, c);
+}
+
+int wt_codes_to_features(const wt_model* m, const int64_t* codes, int32_t K, int32_t B, int64_t L, float* features,
+                         void* stream) {
+    if (!m || !codes || !features) { set_error("wt_codes_to_features: null argument"); return WT_ERR_INVALID; }
+    if (K < 1 || K > m->arch.num_quantizers) { set_error("wt_codes_to_features: K exceeds the number of codebooks"); return WT_ERR_INVALID; }
+    DeviceGuard dg(m->device);
+    if (!dg.ok) { set_error("hipSetDevice failed"); return WT_ERR_HIP; }
+    return launch_codes_to_features(codes, m->embed, K, m->arch.vq_bins, B, L, 512, features, static_cast<hipStream_t>(stream),
+                                    m->bad_codes_dev);
+}
+
+int wt_sconv1d(const float* x, const float* w, const float* bias, float* y, int32_t B, int64_t T, int32_t Cin,
+               int32_t Cout, int32_t k, int32_t stride, int32_t dilation, int32_t elu_input, void* stream) {
+    ConvW cw; cw.w = const_cast<float*>(w); cw.b = const_cast<float*>(bias); cw.cout = Cout; cw.cin = Cin; cw.k = k;
+    GemmArgs a = sconv_args(cw, B, T, stride, dilation);
+    a.A = x; a.C = y;
+    return launch_gemm(a, elu_input ? PRO_ELU : PRO_NONE, EPI_BIAS, static_cast<hipStream_t>(stream));
+}
+
+// Both operands of a single-stage S32 call are split here (the plans' producers write S32 directly), each with a
+// per-tensor power-of-two scale chosen on the device; `tail` = 256 spare bytes after the two S32 arrays
+static int split_pair(const float* w, long nw, const float* x, long nx, char* ws_w, char* ws_x, char* tail, GemmArgs& a,
+                      hipStream_t s) {
+    unsigned* bits = reinterpret_cast<unsigned*>(tail);
+    float* sc = reinterpret_cast<float*>(tail + 16);              // {scale_w, scale_x, 1 / (scale_w * scale_x)}
+    if (int rc = launch_pow2_scales(w, nw, x, nx, bits, sc, s)) return rc;
+    if (int rc = launch_split_s32(w, ws_w, nw, s, sc)) return rc;
+    if (int rc = launch_split_s32(x, ws_x, nx, s, sc + 1)) return rc;
+    a.W_hi = ws_w;
+    a.A = reinterpret_cast<const float*>(ws_x);
+    a.acc_scale_dev = sc + 2;
+    return 0;
+}
+
+int wt_linear(const float* x, const float* w, const float* bias, float* y, int64_t M, int32_t N, int32_t K,
+              int32_t f16x3, void* workspace, void* stream) {
+    if (!x || !w || !y) { set_error("wt_linear: null argument"); return WT_ERR_INVALID; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GemmArgs a = linear_args(w, bias, M, N, K);
+    a.A = x; a.C = y;
+    if (!f16x3) return launch_gemm(a, PRO_NONE, EPI_BIAS, s);
+    if (!workspace) { set_error("wt_linear: the f16x3 modes need a workspace"); return WT_ERR_INVALID; }
+    char* hi = static_cast<char*>(workspace);
+    if (f16x3 == 1) {
+        if (int rc = launch_split_f16x2(w, hi, hi + (size_t)N * K * 2, (long)N * K, s)) return rc;
+        a.W_hi = hi; a.w_lo_off = (long)N * K;
+        return launch_gemm16(a, PRO_NONE, EPI_BIAS, s);
+    }
+    char* xs = hi + (size_t)N * K * 4;
+    if (int rc = split_pair(w, (long)N * K, x, (long)M * K, hi, xs, xs + (size_t)M * K * 4, a, s)) return rc;
+    return launch_gemm16s(a, EPI_BIAS, f16x3 == 3 ? 1 : 0, s);
+}
+
+int wt_conv1d_s32(const float* x, const float* w, const float* bias, float* y, int32_t B, int64_t T, int32_t Cin,
+                  int32_t Cout, int32_t k, int32_t stride, int32_t zero_same, void* workspace, void* stream) {
+    if (!x || !w || !y || !workspace) { set_error("wt_conv1d_s32: null argument"); return WT_ERR_INVALID; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ConvW cw; cw.w = const_cast<float*>(w); cw.b = const_cast<float*>(bias); cw.cout = Cout; cw.cin = Cin; cw.k = k;
+    GemmArgs a = zero_same ? zconv_args(cw, B, (int)T) : sconv_args(cw, B, T, stride, 1);
+    char* ws = static_cast<char*>(workspace);
+    char* xs = ws + (size_t)Cout * k * Cin * 4;
+    if (int rc = split_pair(w, (long)Cout * k * Cin, x, (long)B * T * Cin, ws, xs, xs + (size_t)B * T * Cin * 4, a, s)) return rc;
+    a.C = y;
+    return launch_gemm16s(a, EPI_BIAS, 0, s);
+}
+
+static size_t al256(size_t b) { return (b + 255) / 256 * 256; }
+size_t wt_vq_workspace_bytes(int64_t N, int32_t D, int32_t bins) {
+    const size_t np = std::max(gemm_vq_parts(bins), gemm16s_vq_parts(bins));
+    return al256((size_t)N * D * 4) + al256((size_t)bins * D * 4) + al256((size_t)N * sizeof(float)) +
+           2 * al256((size_t)N * np * sizeof(float)) + al256((size_t)bins * sizeof(float)) + 512;
+}
+
+// the ee[] table here is rebuilt per call on the device by row_sumsq (same kernel as |x|^2)
+static int vq_nearest(const float* x, const float* embed, int64_t N, int32_t D, int32_t bins, int64_t* codes_out,
+                      void* workspace, void* stream, bool s32) {
+    if (!x || !embed || !codes_out || !workspace) { set_error("wt_vq_nearest: null argument"); return WT_ERR_INVALID; }
+    if (s32 && (D % 32)) { set_error("wt_vq_nearest: the split-f16 kernel needs D % 32 == 0"); return WT_ERR_INVALID; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int np = s32 ? gemm16s_vq_parts(bins) : gemm_vq_parts(bins);
+    char* ws = static_cast<char*>(workspace);
+    char* xs = ws; ws += al256((size_t)N * D * 4);
+    char* es = ws; ws += al256((size_t)bins * D * 4);
+    float* xx = reinterpret_cast<float*>(ws); ws += al256((size_t)N * sizeof(float));
+    float* pv = reinterpret_cast<float*>(ws); ws += al256((size_t)N * np * sizeof(float));
+    int* pi = reinterpret_cast<int*>(ws); ws += al256((size_t)N * np * sizeof(float));
+    float* ee = reinterpret_cast<float*>(ws); ws += al256((size_t)bins * sizeof(float));
+    if (int rc = launch_row_sumsq(x, xx, N, D, s)) return rc;
+    if (int rc = launch_row_sumsq(embed, ee, bins, D, s)) return rc;
+    GemmArgs a = linear_args(embed, nullptr, N, bins, D);
+    a.A = x; a.vq_xx = xx; a.vq_ee = ee; a.vq_pval = pv; a.vq_pidx = pi; a.vq_nparts = np;
+    if (s32) {
+        // what the encoder plan launches: distances on gemm16s.hip, per-slab argmax in its epilogue
+        if (int rc = split_pair(embed, (long)bins * D, x, (long)N * D, es, xs, ws, a, s)) return rc;
+        if (int rc = launch_gemm16s(a, EPI_ARGMAX, OUT_F32, s)) return rc;
+    } else {
+        if (int rc = launch_gemm(a, PRO_NONE, EPI_ARGMAX, s)) return rc;
+    }
+    for (int64_t r0 = 0; r0 < N; r0 += 8192) {
+        const int n = (int)std::min<int64_t>(8192, N - r0);
+        if (int rc = launch_vq_finalize(pv + r0 * np, pi + r0 * np, np, embed, codes_out + r0, nullptr, 1, n, D, bins, s)) return rc;
+    }
+    return WT_OK;
+}
+int wt_vq_nearest(const float* x, const float* embed, int64_t N, int32_t D, int32_t bins, int64_t* codes_out,
+                  void* workspace, void* stream) {
+    return vq_nearest(x, embed, N, D, bins, codes_out, workspace, stream, true);
+}
+int wt_vq_nearest_f32(const float* x, const float* embed, int64_t N, int32_t D, int32_t bins, int64_t* codes_out,
+                      void* workspace, void* stream) {
+    return vq_nearest(x, embed, N, D, bins, codes_out, workspace, stream, false);
+}
+
+int wt_resblock(const float* x, const float* wav, const float* e0_w, const float* e0_b, const float* w3, const float* b3,
+                const float* w1, const float* b1, const float* ws, const float* bs, float* y, int32_t B, int64_t T,
+                int32_t C, int32_t elu_out, int32_t out_s32, int32_t fp32_chain, void* stream) {
+    if ((!x && !wav) || !w3 || !b3 || !w1 || !b1 || !ws || !bs || !y) { set_error("wt_resblock: null argument"); return WT_ERR_INVALID; }
+    if (wav && (!e0_w || !e0_b)) { set_error("wt_resblock: the folded first conv needs its weights"); return WT_ERR_INVALID; }
+    if (B < 1 || T < 1 || (long)B * T >= (long)INT_MAX) { set_error("wt_resblock: bad shape"); return WT_ERR_INVALID; }
+    if (fp32_chain && out_s32) { set_error("wt_resblock: the fp32 kernel writes fp32"); return WT_ERR_INVALID; }
+    ResblockArgs a{};
+    a.x = wav ? nullptr : x; a.wav = wav; a.e0_w = e0_w; a.e0_b = e0_b;
+    a.W3 = w3; a.b3 = b3; a.W1 = w1; a.b1 = b1; a.Ws = ws; a.bs = bs;
+    a.y = y; a.B = B; a.T = (int)T; a.C = C; a.elu_out = elu_out ? 1 : 0; a.out_s32 = out_s32 ? 1 : 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return fp32_chain ? launch_resblock(a, s) : launch_resblock16(a, s);
+}
+
+}  // extern "C"

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <mutex>
 #include <string>
 
 namespace wt {
@@ -18,18 +19,45 @@ void set_error(const std::string& msg);
         }                                                                                       \
     } while (0)
 
-// hipFuncSetAttribute (dynamic LDS size) is per device: a process that drives several GPUs must set it on each one
+// hipFuncSetAttribute (dynamic LDS size) is per device: a process that drives several GPUs must set it on each one.
+// run(f) calls f once per device (under a lock: plans may be run from several host threads) and again later if it failed
 struct PerDeviceOnce {
+    std::mutex mu;
     bool seen[64] = {};
-    bool first() {
+    template <class F> int run(F&& f) {
         int d = 0;
         (void)hipGetDevice(&d);
         d &= 63;
-        if (seen[d]) return false;
+        std::lock_guard<std::mutex> g(mu);
+        if (seen[d]) return 0;
+        if (int rc = f()) return rc;
         seen[d] = true;
-        return true;
+        return 0;
     }
 };
+
+// ---------------------------------------------------------------------------------------------
+// Call status.  A plan run owns one 32-bit status word in its workspace (zeroed at the start of the call).  Kernels
+// OR bits into it; the guard step that ends every plan poisons the call's outputs (codes = -1, floats = NaN) when
+// it is non-zero and copies it to a host-visible word, so a failed call can never hand out plausible-looking data.
+//   WT_STATUS_LSTM  : a step barrier of the persistent LSTM timed out (lost co-residency)
+//   WT_STATUS_RANGE : an S32 producer met |v| >= 65504: the f16 hi half of the split representation would be inf
+enum : unsigned { WT_STATUS_LSTM = 1u, WT_STATUS_RANGE = 2u };
+// The launch functions below take the status pointer from this per-thread context, which run_plan sets for the
+// duration of a call (nullptr outside a plan: the single-stage entry points have no status word)
+struct LaunchCtx { unsigned* status = nullptr; };
+extern thread_local LaunchCtx g_launch;
+
+#if defined(__HIPCC__)
+// largest |v| of a value that is being converted to the split-f16 form; NaNs are ignored (they propagate by themselves)
+__device__ __forceinline__ float amax1(float m, float v) { return fmaxf(m, fabsf(v)); }
+__device__ __forceinline__ float amax4(float m, float a, float b, float c, float d) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(a), fabsf(b))), fmaxf(fabsf(c), fabsf(d)));
+}
+__device__ __forceinline__ void range_report(unsigned* status, float amax) {
+    if (status && amax >= 65504.f) __hip_atomic_fetch_or(status, (unsigned)WT_STATUS_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // The one dense-contraction kernel of the path: C = epilogue(prologue(gather(A)) . W^T)
@@ -102,6 +130,9 @@ struct GemmArgs {
     int stage_epi = 0;    // gemm16s: epilogue staged through per-wave LDS scratch at byte offset stage_off (set by the launcher)
     int stage_off = 0;
     int pc_off = 0;       // gemm16s: byte offset of the per-wave bias (and gamma) cache in LDS, 0 = vectors read from global memory
+    float acc_scale = 1.f;                 // gemm16s: the accumulators are multiplied by this (a power of two: operands were
+    const float* acc_scale_dev = nullptr;  // stored scaled) before bias / activation; the device copy, when set, wins
+    unsigned* status = nullptr;            // gemm16s: call status word (range report of the S32 epilogues); launcher default: g_launch
     int dbg = 0;          // gemm16s timing experiments only (WT_GEMM16S_DBG): 1 no DMA in the K loop, 2 no MFMA, 4 no epilogue
 };
 
@@ -114,7 +145,9 @@ int launch_split_f16x2(const float* w, void* hi, void* lo, long n, hipStream_t s
 // footprint and strides as the fp32 array); a.A / a.W_hi point at S32 data, out_s32 selects an S32 C
 int launch_gemm16s(const GemmArgs& a, int epi, int out, hipStream_t s);     // out: Out16s
 int gemm16s_vq_parts(int N);
-int launch_split_s32(const float* x, void* out, long n, hipStream_t s);
+int launch_split_s32(const float* x, void* out, long n, hipStream_t s, const float* scale_dev = nullptr);
+// per-tensor power-of-two scales of two tensors on the device: out3 = {scale_a, scale_b, 1 / (scale_a * scale_b)}
+int launch_pow2_scales(const float* a, long na, const float* b, long nb, unsigned* bits2, float* out3, hipStream_t s);
 
 // ------------------------------------------------------------------------ non-GEMM kernels
 int launch_conv_first(const float* wav, const float* w /*[7][Cout]*/, const float* bias, float* y, int B, long T,
@@ -139,7 +172,10 @@ int launch_row_sumsq(const float* x, float* out, long rows, int D, hipStream_t s
 int launch_vq_finalize(const float* pval, const int* pidx, int nparts, const float* embed, int64_t* codes,
                        float* feat_ncl, int B, int L, int D, int bins, hipStream_t s);
 int launch_codes_to_features(const int64_t* codes, const float* embed, int K, int bins, int B, long L, int D,
-                             float* feat_ncl, hipStream_t s);
+                             float* feat_ncl, hipStream_t s, unsigned* bad = nullptr);
+// last step of every plan: on a non-zero status word poison the outputs (codes = -1, floats = NaN) and publish the bits
+int launch_plan_guard(const unsigned* status, unsigned* host_status, int64_t* codes, long n_codes, float* f0, long n0,
+                      float* f1, long n1, float* f2, long n2, hipStream_t s);
 struct LstmArgs {
     const float* xg0;     // [L][B][4H] (time-major) layer-0 input projection (+ both biases), packed gate order
     const float* W0;      // W_hh_l0, per 16 packed gate rows: [H/16][64 lanes][4] (ops.hip lstm_step_kernel)
@@ -155,6 +191,7 @@ struct LstmArgs {
     int elu_out;          // store elu(h1 + x): the only consumer is ELU -> conv (seanet.py:136-139)
     int out_s32;          // write y in the S32 split-f16 layout (its consumer is a gemm16s conv)
     int f16x3;            // W0 / W1 are the f16 (hi, lo) packings and the state is kept quad-split (ops.hip)
+    unsigned* status = nullptr;   // call status word (range report of the S32 output); launcher default: g_launch
 };
 int launch_lstm_step(const LstmArgs& a, int s, hipStream_t stream);
 // the whole recurrence in one persistent launch (lstm_persist.hip): per-XCD clip groups, weights resident in registers
@@ -166,7 +203,8 @@ struct LstmPersistArgs {
     float* y;             // [B][L][H] output
     void* hx;             // lstm_persist_hx_bytes(): per-XCD exchange buffers  } filled before the launch with 0xFF bytes
     unsigned* ctl;        // lstm_persist_ctl_bytes(): tickets / counters / error } (data_flag) or zeros (counter form)
-    unsigned* host_err;   // optional host-mapped word, set to 1 when a step barrier times out
+    unsigned* status = nullptr;   // call status word: WT_STATUS_LSTM when a step barrier times out, WT_STATUS_RANGE; launcher default: g_launch
+    int dbg_spin_shift = 0;       // test hook: the spin bounds are divided by 2^this
     int B, L, H, Bx;      // Bx = clips per XCD = ceil(B / 8) <= 16
     int elu_out, out_s32;
     int data_flag;        // bit 0: the exchanged state carries its own readiness marks (default), else arrival counter per step;
@@ -192,6 +230,7 @@ struct ResblockArgs {
     int elu_out;          // store elu(y) (the only consumer is ELU -> down conv)
     int out_s32;          // resblock16 only: write y in the S32 split-f16 layout (gemm16s.hip) instead of fp32
     int dbg;              // resblock16 timing experiments only (WT_RB16_DBG)
+    unsigned* status;     // resblock16: call status word (range report of its split-f16 conversions); launcher default: g_launch
 };
 bool resblock_fusable(int C);
 int launch_resblock(const ResblockArgs& a, hipStream_t s);      // fp32 MFMA chain (resblock.hip)

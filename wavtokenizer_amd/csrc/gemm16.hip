@@ -327,10 +327,11 @@ static int launch16_one(const GemmArgs& a, hipStream_t s) {
     const size_t smem = 2ull * (2 * BM + 2 * BN) * PITCH16 * sizeof(_Float16) + (size_t)a.taps * BM * sizeof(unsigned);
     constexpr size_t smem_max = 2ull * (2 * BM + 2 * BN) * PITCH16 * sizeof(_Float16) + 32ull * BM * sizeof(unsigned);
     auto kern = gemm16_kernel<BM, BN, WMs, WNs, PRO, EPI>;
-    if (attr_once.first()) {
+    if (int rc = attr_once.run([&]() -> int {
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)smem_max));
-    }
+        return 0;
+    })) return rc;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, 1, a.nz), dim3(256), smem, s, a);
     WT_HIP_CHECK(hipGetLastError());

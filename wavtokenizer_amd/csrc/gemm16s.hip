@@ -95,7 +95,8 @@ __device__ __forceinline__ void store_s32(_Float16* grp, int slot, float v) {
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // four consecutive elements n .. n+3 (n % 4 == 0) of a row in S32: 8 bytes of hi halves, 8 bytes of lo halves
-__device__ __forceinline__ void store_s32_x4(float* row, int n, const f32x4 v) {
+__device__ __forceinline__ void store_s32_x4(float* row, int n, const f32x4 v, float& amax) {
+    amax = amax4(amax, v.x, v.y, v.z, v.w);
     f16x4 hi, lo;
     hi.x = (_Float16)v.x; hi.y = (_Float16)v.y; hi.z = (_Float16)v.z; hi.w = (_Float16)v.w;
     lo.x = (_Float16)((v.x - (float)hi.x) * 2048.f); lo.y = (_Float16)((v.y - (float)hi.y) * 2048.f);
@@ -314,6 +315,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
     // the epilogue's own loads and stores simply queue behind them.  Past the last tile the DMAs are issued all the
     // same with out-of-range offsets (constant wait counts).
     const int nk = p.K / SBK;
+    float amax = 0.f;            // largest magnitude this wave converts to the split-f16 form (range_report at the end)
+    // operands may carry a per-tensor power-of-two scale (weights at load, the single-stage entry points): the
+    // accumulators are brought back by acc_s, exactly (a power of two), before bias and activation
+    const float acc_s = p.acc_scale_dev ? *p.acc_scale_dev : p.acc_scale;
+    const float lo_s = acc_s * (1.f / 2048.f);
     if ((p.dbg & 64) && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);     // experiment: static priority for the younger half
     build_table(blockIdx.x, 0);
     __syncthreads();
@@ -365,13 +371,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
     const int row_l = lane & 31, col_h = 4 * (lane >> 5);
     const int m_w = bm * BM + wm * WM, n_w = bn * BN + wn * WN;
     float* __restrict__ Cg = p.C + (long)z * p.zC;
-    constexpr float LO_SCALE = 1.f / 2048.f;
     auto acc4 = [&](int i, int j, int g) {
         f32x4 v;
-        v.x = accm[i][j][4 * g + 0] + accc[i][j][4 * g + 0] * LO_SCALE;
-        v.y = accm[i][j][4 * g + 1] + accc[i][j][4 * g + 1] * LO_SCALE;
-        v.z = accm[i][j][4 * g + 2] + accc[i][j][4 * g + 2] * LO_SCALE;
-        v.w = accm[i][j][4 * g + 3] + accc[i][j][4 * g + 3] * LO_SCALE;
+        v.x = fmaf(accc[i][j][4 * g + 0], lo_s, accm[i][j][4 * g + 0] * acc_s);
+        v.y = fmaf(accc[i][j][4 * g + 1], lo_s, accm[i][j][4 * g + 1] * acc_s);
+        v.z = fmaf(accc[i][j][4 * g + 2], lo_s, accm[i][j][4 * g + 2] * acc_s);
+        v.w = fmaf(accc[i][j][4 * g + 3], lo_s, accm[i][j][4 * g + 3] * acc_s);
         return v;
     };
 
@@ -434,8 +439,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
                     }
                     const int f = (pc >> 6) * 32 + (pc & 31);          // bin slot
                     if (OUT == OUT_S32) {
-                        store_s32_x4(crow, f, re);
-                        store_s32_x4(crow, p.head_kb + f, im);
+                        store_s32_x4(crow, f, re, amax);
+                        store_s32_x4(crow, p.head_kb + f, im, amax);
                     } else {
                         *reinterpret_cast<f32x4*>(crow + f) = re;
                         *reinterpret_cast<f32x4*>(crow + p.head_kb + f) = im;
@@ -486,6 +491,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
                                 const int ch = 2 * g + (col_h >> 2);
                                 *reinterpret_cast<f32x4*>(sc + row_l * 128 + ((ch ^ sw_w) * 16)) = v;
                             } else {
+                                amax = amax4(amax, v.x, v.y, v.z, v.w);
                                 f16x4 hi, lo;
                                 hi.x = (_Float16)v.x; hi.y = (_Float16)v.y; hi.z = (_Float16)v.z; hi.w = (_Float16)v.w;
                                 lo.x = (_Float16)((v.x - (float)hi.x) * 2048.f); lo.y = (_Float16)((v.y - (float)hi.y) * 2048.f);
@@ -549,37 +555,77 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
                         const f32x4 gm = *reinterpret_cast<const f32x4*>(pcw + WN * 4 + (n - n_w) * 4);      // EPI_BIAS_GAMMA_RES: always cached
                         v = *reinterpret_cast<const f32x4*>(p.R + (long)m * p.r_rstride + n) + gm * v;
                     }
-                    if (OUT == OUT_S32 || OUT == OUT_S32_DUAL_ELU) store_s32_x4(crow, n, v);
+                    if (OUT == OUT_S32 || OUT == OUT_S32_DUAL_ELU) store_s32_x4(crow, n, v, amax);
                     else *reinterpret_cast<f32x4*>(crow + n) = v;
                     if (OUT == OUT_S32_DUAL_ELU) {
                         f32x4 ev;
                         ev.x = elu_s(v.x); ev.y = elu_s(v.y); ev.z = elu_s(v.z); ev.w = elu_s(v.w);
-                        store_s32_x4(p.C2 + (long)z * p.zC + (long)m * p.c_rstride, n, ev);
+                        store_s32_x4(p.C2 + (long)z * p.zC + (long)m * p.c_rstride, n, ev, amax);
                     } else if (OUT == OUT_F32_AND_S32) {
-                        store_s32_x4(p.C2 + (long)z * p.zC + (long)m * p.c_rstride, n, v);
+                        store_s32_x4(p.C2 + (long)z * p.zC + (long)m * p.c_rstride, n, v, amax);
                     }
                 }
         }
     }
     }   // persistent tile loop
+    range_report(p.status, amax);
     wait_vm_lgkm<0>();
 }
 
 // fp32 -> S32 (flat: rows are multiples of 32 elements, so the layout is a function of the flat index alone)
-__global__ __launch_bounds__(256) void split_s32_kernel(const float* __restrict__ x, _Float16* __restrict__ out, long n) {
+// `scale` (optional, device): the values are multiplied by scale[0], a power of two chosen by pow2_scale_kernel, first
+__global__ __launch_bounds__(256) void split_s32_kernel(const float* __restrict__ x, _Float16* __restrict__ out, long n,
+                                                        const float* __restrict__ scale, unsigned* status) {
+    const float sc = scale ? scale[0] : 1.f;
+    float amax = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const float v = x[i];
+        const float v = x[i] * sc;
+        amax = amax1(amax, v);
         const _Float16 h = (_Float16)v;
         const long g = (i >> 5) * 64 + (i & 31);
         out[g] = h;
         out[g + 32] = (_Float16)((v - (float)h) * 2048.f);
     }
+    range_report(status, amax);
 }
 
-int launch_split_s32(const float* x, void* out, long n, hipStream_t s) {
+int launch_split_s32(const float* x, void* out, long n, hipStream_t s, const float* scale_dev) {
     if (n % 32) { set_error("split_s32: element count must be a multiple of 32"); return -1; }
     int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-    hipLaunchKernelGGL(split_s32_kernel, dim3(blocks), dim3(256), 0, s, x, static_cast<_Float16*>(out), n);
+    hipLaunchKernelGGL(split_s32_kernel, dim3(blocks), dim3(256), 0, s, x, static_cast<_Float16*>(out), n, scale_dev, g_launch.status);
+    WT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// Per-tensor power-of-two scale for the single-stage entry points (the plans' producers write S32 directly, with
+// the overflow report instead): amax_bits_kernel leaves max |x| (as its bit pattern: positive floats order like
+// unsigned integers) in bits[0]; pow2_scale_kernel turns the maxima of two tensors into scale_a, scale_b = powers of two
+// that bring each maximum into [1, 2) (1 for an all-zero or non-finite tensor), and out[2] = 1 / (scale_a * scale_b),
+// the factor that restores the accumulators.
+__global__ __launch_bounds__(256) void amax_bits_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ bits) {
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(bits, __float_as_uint(m));
+}
+__global__ void pow2_scale_kernel(const unsigned* __restrict__ bits, float* __restrict__ out) {
+    float sc[2];
+    for (int i = 0; i < 2; ++i) {
+        const unsigned e = (bits[i] >> 23) & 0xffu;             // biased exponent of the maximum
+        // 2^(127 - e) brings the maximum into [1, 2); keep the scale itself a normal float, and leave zero / inf / NaN alone
+        sc[i] = (e == 0u || e == 255u || e >= 253u) ? 1.f : __uint_as_float((254u - e) << 23);
+    }
+    out[0] = sc[0];
+    out[1] = sc[1];
+    out[2] = (1.f / sc[0]) * (1.f / sc[1]);
+}
+int launch_pow2_scales(const float* a, long na, const float* b, long nb, unsigned* bits2, float* out3, hipStream_t s) {
+    WT_HIP_CHECK(hipMemsetAsync(bits2, 0, 2 * sizeof(unsigned), s));
+    const int ba = (int)((na + 255) / 256 < 2048 ? (na + 255) / 256 : 2048), bb = (int)((nb + 255) / 256 < 2048 ? (nb + 255) / 256 : 2048);
+    hipLaunchKernelGGL(amax_bits_kernel, dim3(ba), dim3(256), 0, s, a, na, bits2);
+    hipLaunchKernelGGL(amax_bits_kernel, dim3(bb), dim3(256), 0, s, b, nb, bits2 + 1);
+    hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1), 0, s, bits2, out3);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -596,10 +642,11 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
     static_assert(stage_bytes + 2 * BM * sizeof(unsigned) <= smem_cap, "LDS budget");
     if (smem > smem_cap) { set_error("gemm16s: too many taps for this tile's LDS budget"); return -1; }
     auto kern = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT>;
-    if (attr_once.first()) {
+    if (int rc = attr_once.run([&]() -> int {
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)smem_max));
-    }
+        return 0;
+    })) return rc;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     const int ntiles = tiles_m * tiles_n;
     // Persistent launch: one workgroup per slot (256 CUs x resident workgroups per CU), each walking tiles
@@ -635,6 +682,7 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
         }
     }
     if (const char* e = getenv("WT_GEMM16S_DBG")) b.dbg = atoi(e);
+    if (!b.status) b.status = g_launch.status;
     hipLaunchKernelGGL(kern, dim3(G, 1, a.nz), dim3(64 * WMs * WNs), smem, s, b);
     WT_HIP_CHECK(hipGetLastError());
     return 0;

@@ -17,6 +17,8 @@
 // workgroup leaves.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace wt {
 
 typedef float f32x4p __attribute__((ext_vector_type(4)));
@@ -112,6 +114,9 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
 
     for (int e = tid; e < HROWS * HPITCH / 16; e += 64 * PW) reinterpret_cast<f32x4p*>(hst)[e] = (f32x4p){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
+    // the spin bounds; a test hook (LstmPersistArgs::dbg_spin_shift) shortens them so that a forced loss of co-residency
+    // is reported within milliseconds
+    const long spin_limit = SPIN_LIMIT >> a.dbg_spin_shift, spin_limit_df = SPIN_LIMIT_DF >> a.dbg_spin_shift;
     const bool tr_on = (a.data_flag & 4) && xcc == 0 && w == 0 && __builtin_amdgcn_readfirstlane(wave) == 0;
     for (int s = 0; s <= L; ++s) {
         LP_TRACE(0);
@@ -163,9 +168,9 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
                         }
                     pend = still;
                     if (pend) {
-                        if (++spin > SPIN_LIMIT_DF || ((spin & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u)) {
+                        if (++spin > spin_limit_df || ((spin & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u)) {
                             __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (a.host_err) __hip_atomic_store(a.host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            if (a.status) __hip_atomic_fetch_or(a.status, (unsigned)WT_STATUS_LSTM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             s_stop = 1;
                             break;
                         }
@@ -200,9 +205,9 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
                 const unsigned want = 32u * (unsigned)s;
                 long spin = 0;
                 while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                    if (++spin > SPIN_LIMIT || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    if (++spin > spin_limit || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                         __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (a.host_err) __hip_atomic_store(a.host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if (a.status) __hip_atomic_fetch_or(a.status, (unsigned)WT_STATUS_LSTM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         s_stop = 1;
                         break;
                     }
@@ -311,6 +316,8 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
                 const float o = a.elu_out ? (yv > 0.f ? yv : __expf(yv) - 1.f) : yv;
                 float* yrow = a.y + (gclip * L + t) * H;
                 if (a.out_s32) {
+                    if (fabsf(o) >= 65504.f && a.status)       // beyond the f16 range of the split form (common.h: WT_STATUS_RANGE)
+                        __hip_atomic_fetch_or(a.status, (unsigned)WT_STATUS_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     _Float16* yp = reinterpret_cast<_Float16*>(yrow) + ((j >> 5) * 64 + (j & 31));
                     const _Float16 oh = (_Float16)o;
                     yp[0] = oh;
@@ -340,21 +347,30 @@ int launch_lstm_persist(const LstmPersistArgs& a, hipStream_t stream) {
     constexpr size_t smem_big = (size_t)16 * HPITCH + (size_t)3 * 4 * 16 * 17 * sizeof(float) + (size_t)PW * LpCfg<false>::NLDS * 1024;
     constexpr size_t smem_small = (size_t)8 * HPITCH + (size_t)3 * 4 * 16 * 17 * sizeof(float) + (size_t)PW * LpCfg<true>::NLDS * 1024;
     static_assert(smem_big + 64 <= 160 * 1024 && smem_small + 64 <= 160 * 1024, "LDS budget");
-    if (attr_once.first()) {
+    if (int rc = attr_once.run([&]() -> int {
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_big));
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_big));
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_small));
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_small));
-    }
+        return 0;
+    })) return rc;
     // the caller has filled hx and ctl with 0xFF bytes (data-flag form) or zeros (counter form)
     const bool small = a.Bx <= 8;
-    const dim3 grid(256), block(64 * PW);
+    LstmPersistArgs b = a;
+    if (!b.status) b.status = g_launch.status;
+    // Test hook (tests/test_gpu_parity.py::test_persistent_lstm_lost_coresidency): WT_LSTM_PERSIST_FAULT=1 launches 8
+    // workgroups too few, so every XCD waits for a 32nd workgroup that never comes, and shortens the spin bounds; the
+    // kernel must then report WT_STATUS_LSTM instead of handing out a half-written sequence
+    const char* fault = getenv("WT_LSTM_PERSIST_FAULT");
+    const bool forced = fault && fault[0] == '1';
+    if (forced) b.dbg_spin_shift = 8;
+    const dim3 grid(forced ? 248 : 256), block(64 * PW);
     if (a.data_flag) {
-        if (small) hipLaunchKernelGGL((lstm_persist_kernel<true, true>), grid, block, smem_small, stream, a);
-        else hipLaunchKernelGGL((lstm_persist_kernel<true, false>), grid, block, smem_big, stream, a);
+        if (small) hipLaunchKernelGGL((lstm_persist_kernel<true, true>), grid, block, smem_small, stream, b);
+        else hipLaunchKernelGGL((lstm_persist_kernel<true, false>), grid, block, smem_big, stream, b);
     } else {
-        if (small) hipLaunchKernelGGL((lstm_persist_kernel<false, true>), grid, block, smem_small, stream, a);
-        else hipLaunchKernelGGL((lstm_persist_kernel<false, false>), grid, block, smem_big, stream, a);
+        if (small) hipLaunchKernelGGL((lstm_persist_kernel<false, true>), grid, block, smem_small, stream, b);
+        else hipLaunchKernelGGL((lstm_persist_kernel<false, false>), grid, block, smem_big, stream, b);
     }
     WT_HIP_CHECK(hipGetLastError());
     return 0;

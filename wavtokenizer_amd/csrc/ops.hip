@@ -15,13 +15,15 @@ __device__ __forceinline__ float wave_sum(float v) {
 typedef _Float16 f16x4s __attribute__((ext_vector_type(4)));
 // S32 layout of gemm16s.hip: every 32 fp32 elements of a row become 128 bytes [32 x f16 hi | 32 x f16 lo],
 // x = hi + lo * 2^-11; element e of a row -> half index (e >> 5) * 64 + (e & 31), lo 32 halves later
-__device__ __forceinline__ void store_s32_1(float* row_base, int e, float v) {
+__device__ __forceinline__ void store_s32_1(float* row_base, int e, float v, float& amax) {
+    amax = amax1(amax, v);
     _Float16* p = reinterpret_cast<_Float16*>(row_base) + ((e >> 5) * 64 + (e & 31));
     const _Float16 h = (_Float16)v;
     p[0] = h;
     p[32] = (_Float16)((v - (float)h) * 2048.f);
 }
-__device__ __forceinline__ void store_s32_4(float* row_base, int e, const f32x4 v) {   // e % 4 == 0
+__device__ __forceinline__ void store_s32_4(float* row_base, int e, const f32x4 v, float& amax) {   // e % 4 == 0
+    amax = amax4(amax, v.x, v.y, v.z, v.w);
     f16x4s hi, lo;
     hi.x = (_Float16)v.x; hi.y = (_Float16)v.y; hi.z = (_Float16)v.z; hi.w = (_Float16)v.w;
     lo.x = (_Float16)((v.x - (float)hi.x) * 2048.f); lo.y = (_Float16)((v.y - (float)hi.y) * 2048.f);
@@ -193,8 +195,9 @@ int launch_conv_last(const float* x, const float* w, const float* bias, float* y
 // ------------------------------------------------------------------------------------ transpose
 // [B][R][C] -> [B][C][R] through a padded 32x32 LDS tile (coalesced on both sides).
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R,
-                                                        int C, int s32) {
+                                                        int C, int s32, unsigned* status) {
     __shared__ float tile[32][33];
+    float amax = 0.f;
     const long boff = (long)blockIdx.z * R * C;
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
@@ -206,16 +209,17 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     for (int i = ty; i < 32; i += 8) {
         const int c = c0 + i, r = r0 + tx;
         if (r < R && c < C) {
-            if (s32) store_s32_1(out + boff + (long)c * R, r, tile[tx][i]);
+            if (s32) store_s32_1(out + boff + (long)c * R, r, tile[tx][i], amax);
             else out[boff + (long)c * R + r] = tile[tx][i];
         }
     }
+    range_report(status, amax);
 }
 
 int launch_transpose(const float* in, float* out, int B, int R, int C, hipStream_t s, int out_s32) {
     if (out_s32 && (R % 32)) { set_error("transpose: an S32 output needs rows in multiples of 32 elements"); return -1; }
     dim3 grid((C + 31) / 32, (R + 31) / 32, B);
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, in, out, R, C, out_s32);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, in, out, R, C, out_s32, g_launch.status);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -230,8 +234,9 @@ template <int APPLY>   // 0: scale/shift only; 1: y = x*scale + shift; 2: y = sw
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float* __restrict__ scale,
                                                        float* __restrict__ shift, float* __restrict__ y, int L, int C,
-                                                       int cg, float eps, int s32) {
+                                                       int cg, float eps, int s32, unsigned* status) {
     __shared__ float red[4];
+    float amax = 0.f;
     __shared__ float s_mean, s_rstd;
     const int g = blockIdx.x, b = blockIdx.y;
     const float* xb = x + (long)b * L * C + g * cg;
@@ -274,9 +279,10 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
             const float sc = rstd * gamma[g * cg + j];
             float v = xb[(long)t * C + j] * sc + (beta[g * cg + j] - mean * sc);
             if (APPLY == 2) v = v / (1.f + expf(-v));
-            if (s32) store_s32_1(y + ((long)b * L + t) * C, g * cg + j, v);
+            if (s32) store_s32_1(y + ((long)b * L + t) * C, g * cg + j, v, amax);
             else yb[(long)t * C + j] = v;
         }
+        range_report(status, amax);
     }
 }
 
@@ -289,7 +295,7 @@ int launch_gn_stats(const float* x, const float* gamma, const float* beta, float
     if (part && L > 256 && GBs && (cgs % 4 == 0) && (C % 4 == 0) && GBs <= 8)
         return launch_gn_chunked(x, gamma, beta, scale, shift, nullptr, 0, B, L, C, groups, GBs, eps, s, 0, part);
     hipLaunchKernelGGL(gn_stats_kernel<0>, dim3(groups, B), dim3(256), 0, s, x, gamma, beta, scale, shift,
-                       (float*)nullptr, L, C, C / groups, eps, 0);
+                       (float*)nullptr, L, C, C / groups, eps, 0, (unsigned*)nullptr);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -302,8 +308,9 @@ template <int SWISH>
 __global__ __launch_bounds__(512) void gn_tile_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float* __restrict__ scale,
                                                       float* __restrict__ shift, float* __restrict__ y, int L, int C,
-                                                      int cg, int GB, float eps, int s32) {
+                                                      int cg, int GB, float eps, int s32, unsigned* status) {
     extern __shared__ __attribute__((aligned(16))) float tile[];      // [L][W], W = GB * cg
+    float amax = 0.f;
     __shared__ float s_sc[128], s_sh[128], s_red[8];
     const int NT = blockDim.x;                             // 256, or 512 for slabs so large that one workgroup fills the CU
     const int W = GB * cg, W4 = W / 4;
@@ -396,10 +403,11 @@ __global__ __launch_bounds__(512) void gn_tile_kernel(const float* __restrict__ 
                 o.x *= __builtin_amdgcn_rcpf(1.f + __expf(-o.x)); o.y *= __builtin_amdgcn_rcpf(1.f + __expf(-o.y));
                 o.z *= __builtin_amdgcn_rcpf(1.f + __expf(-o.z)); o.w *= __builtin_amdgcn_rcpf(1.f + __expf(-o.w));
             }
-            if (s32) store_s32_4(yb + (long)t * C, c0 + q * 4, o);
+            if (s32) store_s32_4(yb + (long)t * C, c0 + q * 4, o, amax);
             else *reinterpret_cast<f32x4*>(yb + (long)t * C + c0 + q * 4) = o;
         }
     }
+    range_report(status, amax);
 }
 
 // GroupNorm for sequences too long for one LDS slab (30 s clips: L = 1200): the L x 96-channel slab is cut into chunks of
@@ -451,8 +459,9 @@ __global__ __launch_bounds__(256) void gn_chunk_apply_kernel(const float* __rest
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ scale, float* __restrict__ shift,
                                                              float* __restrict__ y, int L, int C, int cg, int GB, int groups,
-                                                             int nch, float eps, int s32) {
+                                                             int nch, float eps, int s32, unsigned* status) {
     __shared__ float s_mean[8], s_rstd[8], s_sc[128], s_sh[128];
+    float amax = 0.f;
     const int W = GB * cg, W4 = W / 4;
     const int c0 = blockIdx.x * W, k = blockIdx.y, b = blockIdx.z;
     if (threadIdx.x < GB) {
@@ -489,9 +498,10 @@ __global__ __launch_bounds__(256) void gn_chunk_apply_kernel(const float* __rest
             o.x *= __builtin_amdgcn_rcpf(1.f + __expf(-o.x)); o.y *= __builtin_amdgcn_rcpf(1.f + __expf(-o.y));
             o.z *= __builtin_amdgcn_rcpf(1.f + __expf(-o.z)); o.w *= __builtin_amdgcn_rcpf(1.f + __expf(-o.w));
         }
-        if (s32) store_s32_4(yb + (long)t * C, c0 + q * 4, o);
+        if (s32) store_s32_4(yb + (long)t * C, c0 + q * 4, o, amax);
         else *reinterpret_cast<f32x4*>(yb + (long)t * C + c0 + q * 4) = o;
     }
+    range_report(status, amax);
 }
 
 size_t gn_part_floats(int B, int L, int groups) { return (size_t)B * groups * ((L + GN_CH - 1) / GN_CH) * 2; }
@@ -503,13 +513,12 @@ static int launch_gn_chunked(const float* x, const float* gamma, const float* be
     const int cg = C / groups, nch = (L + GN_CH - 1) / GN_CH;
     const size_t smem = (size_t)GN_CH * GB * cg * sizeof(float);
     static PerDeviceOnce attr_once;
-    if (attr_once.first())
-        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gn_chunk_stats_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    if (int rc = attr_once.run([&]() -> int { WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gn_chunk_stats_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); return 0; })) return rc;
     hipLaunchKernelGGL(gn_chunk_stats_kernel, dim3(groups / GB, nch, B), dim3(256), smem, s, x, part, L, C, cg, GB, groups, nch);
     const dim3 grid(groups / GB, mode ? nch : 1, B);
-    if (mode == 0) hipLaunchKernelGGL(gn_chunk_apply_kernel<0>, grid, dim3(256), 0, s, x, part, gamma, beta, scale, shift, y, L, C, cg, GB, groups, nch, eps, out_s32);
-    else if (mode == 1) hipLaunchKernelGGL(gn_chunk_apply_kernel<1>, grid, dim3(256), 0, s, x, part, gamma, beta, scale, shift, y, L, C, cg, GB, groups, nch, eps, out_s32);
-    else hipLaunchKernelGGL(gn_chunk_apply_kernel<2>, grid, dim3(256), 0, s, x, part, gamma, beta, scale, shift, y, L, C, cg, GB, groups, nch, eps, out_s32);
+    if (mode == 0) hipLaunchKernelGGL(gn_chunk_apply_kernel<0>, grid, dim3(256), 0, s, x, part, gamma, beta, scale, shift, y, L, C, cg, GB, groups, nch, eps, out_s32, g_launch.status);
+    else if (mode == 1) hipLaunchKernelGGL(gn_chunk_apply_kernel<1>, grid, dim3(256), 0, s, x, part, gamma, beta, scale, shift, y, L, C, cg, GB, groups, nch, eps, out_s32, g_launch.status);
+    else hipLaunchKernelGGL(gn_chunk_apply_kernel<2>, grid, dim3(256), 0, s, x, part, gamma, beta, scale, shift, y, L, C, cg, GB, groups, nch, eps, out_s32, g_launch.status);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -531,15 +540,16 @@ int launch_gn_apply(const float* x, const float* gamma, const float* beta, float
     if (GB && (cg % 4 == 0) && (size_t)L * GB * cg * 4 <= 96 * 1024 && (C % 4 == 0)) {
         const size_t smem = (size_t)L * GB * cg * sizeof(float);
         static PerDeviceOnce attr_once;
-        if (attr_once.first()) {
+        if (int rc = attr_once.run([&]() -> int {
             WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gn_tile_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
             WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gn_tile_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        }
+        return 0;
+    })) return rc;
         dim3 grid(groups / GB, B);
         // a slab above 48 KB leaves room for one or two workgroups per CU: give each 8 waves (two per group) then
         const int nt = (smem > 48 * 1024 && GB == 4) ? 512 : 256;
-        if (swish) hipLaunchKernelGGL(gn_tile_kernel<1>, grid, dim3(nt), smem, s, x, gamma, beta, scale, shift, y, L, C, cg, GB, eps, out_s32);
-        else hipLaunchKernelGGL(gn_tile_kernel<0>, grid, dim3(nt), smem, s, x, gamma, beta, scale, shift, y, L, C, cg, GB, eps, out_s32);
+        if (swish) hipLaunchKernelGGL(gn_tile_kernel<1>, grid, dim3(nt), smem, s, x, gamma, beta, scale, shift, y, L, C, cg, GB, eps, out_s32, g_launch.status);
+        else hipLaunchKernelGGL(gn_tile_kernel<0>, grid, dim3(nt), smem, s, x, gamma, beta, scale, shift, y, L, C, cg, GB, eps, out_s32, g_launch.status);
         WT_HIP_CHECK(hipGetLastError());
         return 0;
     }
@@ -547,10 +557,10 @@ int launch_gn_apply(const float* x, const float* gamma, const float* beta, float
         return launch_gn_chunked(x, gamma, beta, scale, shift, y, swish ? 2 : 1, B, L, C, groups, GB, eps, s, out_s32, part);
     if (swish)
         hipLaunchKernelGGL(gn_stats_kernel<2>, dim3(groups, B), dim3(256), 0, s, x, gamma, beta, scale, shift, y, L, C,
-                           C / groups, eps, out_s32);
+                           C / groups, eps, out_s32, g_launch.status);
     else
         hipLaunchKernelGGL(gn_stats_kernel<1>, dim3(groups, B), dim3(256), 0, s, x, gamma, beta, scale, shift, y, L, C,
-                           C / groups, eps, out_s32);
+                           C / groups, eps, out_s32, g_launch.status);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -567,9 +577,10 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
                                                       const float* __restrict__ in_scale,
                                                       const float* __restrict__ in_shift,
                                                       const float* __restrict__ out_scale,
-                                                      const float* __restrict__ out_shift, float eps, int s32) {
+                                                      const float* __restrict__ out_shift, float eps, int s32, unsigned* status) {
     constexpr int C = NV * 256;
     const int lane = threadIdx.x & 63;
+    float amax = 0.f;
     const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
     const long b = m / L;
@@ -617,9 +628,10 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
         const f32x4 os = *reinterpret_cast<const f32x4*>(out_scale + c);
         const f32x4 oh = *reinterpret_cast<const f32x4*>(out_shift + c);
         const f32x4 o = ((v[i] - mean) * rstd) * os + oh;
-        if (s32) store_s32_4(y + m * C, c, o);       // the consumer is the S32 split-f16 GEMM
+        if (s32) store_s32_4(y + m * C, c, o, amax);       // the consumer is the S32 split-f16 GEMM
         else *reinterpret_cast<f32x4*>(y + m * C + c) = o;
     }
+    range_report(status, amax);
 }
 
 // RN_DWCONV with each wave producing R consecutive frames of one clip: the R + 6 input rows and the 7 tap rows are
@@ -629,9 +641,10 @@ template <int NV, int R>
 __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int L,
                                                         const float* __restrict__ dw_w, const float* __restrict__ dw_b,
                                                         const float* __restrict__ out_scale,
-                                                        const float* __restrict__ out_shift, float eps, int s32) {
+                                                        const float* __restrict__ out_shift, float eps, int s32, unsigned* status) {
     constexpr int C = NV * 256;
     const int lane = threadIdx.x & 63;
+    float amax = 0.f;
     const int per_clip = (L + R - 1) / R;
     const long wq = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wq >= (long)B * per_clip) return;
@@ -683,10 +696,11 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict_
             const f32x4 os = *reinterpret_cast<const f32x4*>(out_scale + c);
             const f32x4 oh = *reinterpret_cast<const f32x4*>(out_shift + c);
             const f32x4 o = ((v[r][i] - mean) * rstd) * os + oh;
-            if (s32) store_s32_4(yrow, c, o);
+            if (s32) store_s32_4(yrow, c, o, amax);
             else *reinterpret_cast<f32x4*>(yrow + c) = o;
         }
     }
+    range_report(status, amax);
 }
 
 template <int NV>
@@ -699,12 +713,12 @@ static int launch_rownorm_nv(int mode, const float* x, float* y, long M, int L, 
         const int B = (int)(M / L);
         const long waves = (long)B * ((L + R - 1) / R);
         hipLaunchKernelGGL((dwconv_ln_kernel<NV, R>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, y, B, L, dw_w, dw_b,
-                           os, oh, eps, s32);
+                           os, oh, eps, s32, g_launch.status);
     }
     else if (mode == RN_PLAIN)
-        hipLaunchKernelGGL((rownorm_kernel<NV, RN_PLAIN>), grid, dim3(256), 0, s, x, y, M, L, dw_w, dw_b, is, ih, os, oh, eps, s32);
+        hipLaunchKernelGGL((rownorm_kernel<NV, RN_PLAIN>), grid, dim3(256), 0, s, x, y, M, L, dw_w, dw_b, is, ih, os, oh, eps, s32, g_launch.status);
     else
-        hipLaunchKernelGGL((rownorm_kernel<NV, RN_AFFINE_IN>), grid, dim3(256), 0, s, x, y, M, L, dw_w, dw_b, is, ih, os, oh, eps, s32);
+        hipLaunchKernelGGL((rownorm_kernel<NV, RN_AFFINE_IN>), grid, dim3(256), 0, s, x, y, M, L, dw_w, dw_b, is, ih, os, oh, eps, s32, g_launch.status);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -741,7 +755,8 @@ __global__ __launch_bounds__(256) void softmax_kernel(float* __restrict__ S, lon
     }
     sum = wave_sum(sum);
     if (P_s32) {        // probabilities for a split-f16 GEMM: S32 rows in a separate buffer (pad columns zero)
-        for (int j = lane; j < ld; j += 64) store_s32_1(P_s32 + r * ld, j, j < L ? row[j] / sum : 0.f);
+        float unused = 0.f;                                      // probabilities never leave [0, 1]
+        for (int j = lane; j < ld; j += 64) store_s32_1(P_s32 + r * ld, j, j < L ? row[j] / sum : 0.f, unused);
     } else {
         for (int j = lane; j < ld; j += 64) row[j] = j < L ? row[j] / sum : 0.f;
     }
@@ -798,6 +813,33 @@ int launch_istft_ola(const float* parts, const float* win, const float* wsq, flo
     int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipLaunchKernelGGL(istft_ola_kernel, dim3(blocks), dim3(256), 0, s, parts, win, wsq, out, total, (long)B * L, L, n_fft,
                        hop, Kq);
+    WT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------- call guard
+// The last step of every plan.  status == 0 (the normal case): each workgroup reads one word and leaves.  Otherwise
+// (common.h: WT_STATUS_*) the call's outputs are overwritten — codes with -1, float outputs with NaN — so that a
+// failed call can never hand out plausible-looking data, and the bits are OR-ed into the plan's host-visible word,
+// where the next host call on the plan (or wt_plan_status) finds them.
+__global__ __launch_bounds__(256) void plan_guard_kernel(const unsigned* __restrict__ status, unsigned* host_status,
+                                                         int64_t* codes, long n_codes, float* f0, long n0, float* f1, long n1,
+                                                         float* f2, long n2) {
+    const unsigned st = *status;
+    if (st == 0u) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && host_status)
+        __hip_atomic_fetch_or(host_status, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const long step = (long)gridDim.x * blockDim.x, i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const float qnan = __builtin_nanf("");
+    if (codes) for (long i = i0; i < n_codes; i += step) codes[i] = -1;
+    if (f0) for (long i = i0; i < n0; i += step) f0[i] = qnan;
+    if (f1) for (long i = i0; i < n1; i += step) f1[i] = qnan;
+    if (f2) for (long i = i0; i < n2; i += step) f2[i] = qnan;
+}
+
+int launch_plan_guard(const unsigned* status, unsigned* host_status, int64_t* codes, long n_codes, float* f0, long n0,
+                      float* f1, long n1, float* f2, long n2, hipStream_t s) {
+    hipLaunchKernelGGL(plan_guard_kernel, dim3(256), dim3(256), 0, s, status, host_status, codes, n_codes, f0, n0, f1, n1, f2, n2);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -899,10 +941,13 @@ int launch_vq_finalize(const float* pval, const int* pidx, int nparts, const flo
 }
 
 // WavTokenizer.codes_to_features (decoder/pretrained.py:227-237): sum over the K codebooks of
-// embed[codes[k] + k*bins], transposed to (B, D, L).  Out-of-range codes are clamped.
+// embed[codes[k] + k*bins], transposed to (B, D, L).  F.embedding (pretrained.py:236) raises on an index outside
+// the table; here such a code never reaches the gather (row 0 is read instead), the frame's features become NaN and
+// `bad` (optional) is set to 1, which the host side turns into the error.
 __global__ __launch_bounds__(256) void codes_to_features_kernel(const int64_t* __restrict__ codes,
                                                                 const float* __restrict__ embed, int K, int bins,
-                                                                long L, int D, float* __restrict__ feat, int cchunk) {
+                                                                long L, int D, float* __restrict__ feat, int cchunk,
+                                                                unsigned* bad) {
     const int b = blockIdx.x, B = gridDim.x;
     const int c0 = blockIdx.y * cchunk;
     const long t0 = (long)blockIdx.z * 1024;
@@ -915,18 +960,19 @@ __global__ __launch_bounds__(256) void codes_to_features_kernel(const int64_t* _
         float acc = 0.f;
         for (int k = 0; k < K; ++k) {
             long code = codes[((long)k * B + b) * L + t];
-            code = code < 0 ? 0 : (code >= bins ? bins - 1 : code);
-            acc += embed[((long)k * bins + code) * D + c];
+            const bool oob = code < 0 || code >= bins;
+            if (oob) { code = 0; if (bad) __hip_atomic_store(bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+            acc += oob ? __builtin_nanf("") : embed[((long)k * bins + code) * D + c];
         }
         feat[((long)b * D + c) * L + t] = acc;
     }
 }
 
 int launch_codes_to_features(const int64_t* codes, const float* embed, int K, int bins, int B, long L, int D,
-                             float* feat_ncl, hipStream_t s) {
+                             float* feat_ncl, hipStream_t s, unsigned* bad) {
     const int cchunk = 64;
     dim3 grid(B, (D + cchunk - 1) / cchunk, (unsigned)((L + 1023) / 1024));
-    hipLaunchKernelGGL(codes_to_features_kernel, grid, dim3(256), 0, s, codes, embed, K, bins, L, D, feat_ncl, cchunk);
+    hipLaunchKernelGGL(codes_to_features_kernel, grid, dim3(256), 0, s, codes, embed, K, bins, L, D, feat_ncl, cchunk, bad);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1108,8 +1154,11 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(const LstmAr
     if (layer) {
         const float yv = h + x_skip;                    // lstm.py:37-38 skip
         const float o = a.elu_out ? (yv > 0.f ? yv : __expf(yv) - 1.f) : yv;
-        if (a.out_s32) store_s32_1(a.y + ((long)cb * L + t) * H, j, o);
-        else a.y[((long)cb * L + t) * H + j] = o;
+        if (a.out_s32) {
+            float amax = 0.f;
+            store_s32_1(a.y + ((long)cb * L + t) * H, j, o, amax);
+            range_report(a.status, amax);
+        } else a.y[((long)cb * L + t) * H + j] = o;
     }
 }
 
@@ -1119,8 +1168,10 @@ int launch_lstm_step(const LstmArgs& a, int s, hipStream_t stream) {
     dim3 grid(2 * (a.H / 4), (a.B + 63) / 64);
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("WT_LSTM_DBG"); dbg = e ? atoi(e) : 0; }
-    if (a.f16x3) hipLaunchKernelGGL(lstm_step_kernel<true>, grid, dim3(64 * LSTM_WAVES), 0, stream, a, s | (dbg << 16));
-    else hipLaunchKernelGGL(lstm_step_kernel<false>, grid, dim3(64 * LSTM_WAVES), 0, stream, a, s | (dbg << 16));
+    LstmArgs b = a;
+    if (!b.status) b.status = g_launch.status;
+    if (a.f16x3) hipLaunchKernelGGL(lstm_step_kernel<true>, grid, dim3(64 * LSTM_WAVES), 0, stream, b, s | (dbg << 16));
+    else hipLaunchKernelGGL(lstm_step_kernel<false>, grid, dim3(64 * LSTM_WAVES), 0, stream, b, s | (dbg << 16));
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -237,10 +237,11 @@ static int launch_rb(const ResblockArgs& a, hipStream_t s) {
     static PerDeviceOnce attr_once;
     constexpr size_t smem = (size_t)RbLayout<C, ROWS>::total * sizeof(float);
     auto kern = resblock_kernel<C, ROWS>;
-    if (attr_once.first()) {
+    if (int rc = attr_once.run([&]() -> int {
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)smem));
-    }
+        return 0;
+    })) return rc;
     const long tiles = (long)a.B * ((a.T + ROWS - 1) / ROWS);
     const int per_cu = (int)(160 * 1024 / smem) < 4 ? (int)(160 * 1024 / smem) : 4;
     const long grid = tiles < 256L * per_cu ? tiles : 256L * per_cu;

@@ -24,7 +24,8 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float rb16_elu(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
 
-__device__ __forceinline__ void rb16_split8(const float* v, f16x8& hi, f16x8& lo) {
+__device__ __forceinline__ void rb16_split8(const float* v, f16x8& hi, f16x8& lo, float& amax) {
+    amax = amax4(amax4(amax, v[0], v[1], v[2], v[3]), v[4], v[5], v[6], v[7]);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const _Float16 h = (_Float16)v[i];
@@ -32,7 +33,8 @@ __device__ __forceinline__ void rb16_split8(const float* v, f16x8& hi, f16x8& lo
         lo[i] = (_Float16)((v[i] - (float)h) * 2048.f);
     }
 }
-__device__ __forceinline__ void rb16_split4(const f32x4 v, f16x4& hi, f16x4& lo) {
+__device__ __forceinline__ void rb16_split4(const f32x4 v, f16x4& hi, f16x4& lo, float& amax) {
+    amax = amax4(amax, v[0], v[1], v[2], v[3]);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const _Float16 h = (_Float16)v[i];
@@ -97,6 +99,7 @@ __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs
     float* bb = reinterpret_cast<float*>(smem16 + L::off_b);
     float* wtile = reinterpret_cast<float*>(smem16 + L::off_wav);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float amax = 0.f, wmax = 0.f;        // largest activation / weight magnitude converted to the split-f16 form
 
     // ---- resident split weights.  W3 [H][3][C] -> rows n < H (n >= H: zero padding), k = tap*C + ci;
     //      W2 = [W1 (C x H) | Ws (C x C)] -> rows n < C, k < H from conv1, then the shortcut
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = n < L::H ? a.W3[(long)n * L::K1 + k8 + i] : 0.f;
         f16x8 hi, lo;
-        rb16_split8(v, hi, lo);
+        rb16_split8(v, hi, lo, wmax);
         *reinterpret_cast<f16x8*>(w3 + rb16_woff(L::N1, k8 / 16, 0, n, (k8 / 8) & 1)) = hi;
         *reinterpret_cast<f16x8*>(w3 + rb16_woff(L::N1, k8 / 16, 1, n, (k8 / 8) & 1)) = lo;
     }
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs
         for (int i = 0; i < 8; ++i)
             v[i] = k8 < L::H ? a.W1[(long)n * L::H + k8 + i] : a.Ws[(long)n * C + (k8 - L::H) + i];
         f16x8 hi, lo;
-        rb16_split8(v, hi, lo);
+        rb16_split8(v, hi, lo, wmax);
         *reinterpret_cast<f16x8*>(w2 + rb16_woff(C, k8 / 16, 0, n, (k8 / 8) & 1)) = hi;
         *reinterpret_cast<f16x8*>(w2 + rb16_woff(C, k8 / 16, 1, n, (k8 / 8) & 1)) = lo;
     }
@@ -169,14 +172,15 @@ __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs
     auto put_item = [&](int r, int c8, const float* v) {
         f16x8 hi, lo;
         if (r >= 1 && r <= ROWS) {
-            rb16_split8(v, hi, lo);
+            rb16_split8(v, hi, lo, amax);
             *reinterpret_cast<f16x8*>(xr + XR::off(r - 1, c8, 0)) = hi;
             *reinterpret_cast<f16x8*>(xr + XR::off(r - 1, c8, 1)) = lo;
         }
         float ev[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) ev[i] = rb16_elu(v[i]);
-        rb16_split8(ev, hi, lo);
+        float unused = 0.f;                  // |elu(v)| <= |v|, which the raw split above has covered (or, for the halo rows, a neighbouring tile's)
+        rb16_split8(ev, hi, lo, unused);
         *reinterpret_cast<f16x8*>(xe + XR::off(r, c8, 0)) = hi;
         *reinterpret_cast<f16x8*>(xe + XR::off(r, c8, 1)) = lo;
     };
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs
                     for (int i = 0; i < 4; ++i)
                         v[i] = rb16_elu(a1m[j][4 * g + i] + a1c[j][4 * g + i] * LO_SCALE + bb[n + i]);
                     f16x4 hi, lo;
-                    rb16_split4(v, hi, lo);
+                    rb16_split4(v, hi, lo, amax);
                     *reinterpret_cast<f16x4*>(he + HR::off(row0 + fl, n & ~7, 0) + (n & 7) * 2) = hi;
                     *reinterpret_cast<f16x4*>(he + HR::off(row0 + fl, n & ~7, 1) + (n & 7) * 2) = lo;
                 }
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs
                     }
                     if (a.out_s32) {                                // S32: chunk (n/32)*8 + n%32/8 holds hi, + 4 holds lo
                         f16x4 hi, lo;
-                        rb16_split4(v, hi, lo);
+                        rb16_split4(v, hi, lo, amax);
                         const int ch = (n >> 5) * 8 + ((n & 31) >> 3);
                         *reinterpret_cast<f16x4*>(st + fl * XR::bytes + ((ch ^ XR::swz(fl)) * 16) + (n & 7) * 2) = hi;
                         *reinterpret_cast<f16x4*>(st + fl * XR::bytes + (((ch + 4) ^ XR::swz(fl)) * 16) + (n & 7) * 2) = lo;
@@ -372,6 +376,7 @@ __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs
             }
         }
     }
+    range_report(a.status, fmaxf(amax, wmax));
 }
 
 template <int C, int ROWS, int FOLD>
@@ -380,15 +385,17 @@ static int launch_rb16(const ResblockArgs& a, hipStream_t s) {
     constexpr size_t smem = (size_t)Rb16Layout<C, ROWS>::total;
     static_assert(smem <= 160 * 1024, "LDS budget");
     auto kern = resblock16_kernel<C, ROWS, FOLD>;
-    if (attr_once.first()) {
+    if (int rc = attr_once.run([&]() -> int {
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)smem));
-    }
+        return 0;
+    })) return rc;
     const long tiles = (long)a.B * ((a.T + ROWS - 1) / ROWS);
     const int per_cu = (int)(160 * 1024 / smem) < 4 ? (int)(160 * 1024 / smem) : 4;
     const long grid = tiles < 256L * per_cu ? tiles : 256L * per_cu;
     ResblockArgs b = a;
     if (const char* e = getenv("WT_RB16_DBG")) b.dbg = atoi(e);
+    if (!b.status) b.status = g_launch.status;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(ROWS * 2), smem, s, b);
     WT_HIP_CHECK(hipGetLastError());
     return 0;

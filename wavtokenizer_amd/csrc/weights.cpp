@@ -1,0 +1,538 @@
+// Weight folding / packing, done once at wt_model_create: weight-norm fold (fp64), conv repacking to [Cout][tap][Cin],
+// LSTM gate-row packings (fp32 and split-f16 per-lane forms), the packed ISTFT head and inverse-DFT basis, and the
+// split-f16 (S32 / f16x2) copies of every GEMM weight.
+#include "model.h"
+
+namespace wt {
+
+static int upload(wt_model* M, const std::vector<float>& h, float** out) {
+    void* d = nullptr;
+    size_t bytes = std::max<size_t>(h.size(), 4) * sizeof(float);
+    WT_HIP_CHECK(hipMalloc(&d, bytes));
+    M->allocs.push_back(d);
+    WT_HIP_CHECK(hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    M->weight_bytes += (int64_t)h.size() * sizeof(float);
+    *out = static_cast<float*>(d);
+    return 0;
+}
+static int upload_raw(wt_model* M, const float* src, int64_t n, float** out) {
+    std::vector<float> h(src, src + n);
+    return upload(M, h, out);
+}
+
+// weight_norm fold (torch.nn.utils.weight_norm, dim=0; conv.py:25-34): w[o] = g[o] * v[o] / ||v[o]||
+static std::vector<float> fold_wn(const float* g, const float* v, int d0, int64_t inner) {
+    std::vector<float> w((size_t)d0 * inner);
+    for (int o = 0; o < d0; ++o) {
+        double ss = 0.0;
+        for (int64_t i = 0; i < inner; ++i) { double x = v[o * inner + i]; ss += x * x; }
+        const double sc = (double)g[o] / std::sqrt(ss);
+        for (int64_t i = 0; i < inner; ++i) w[o * inner + i] = (float)(sc * (double)v[o * inner + i]);
+    }
+    return w;
+}
+
+// [cout][cin][k] -> [cout][k][cin]
+static std::vector<float> repack_ock(const std::vector<float>& w, int cout, int cin, int k) {
+    std::vector<float> o(w.size());
+    for (int a = 0; a < cout; ++a)
+        for (int c = 0; c < cin; ++c)
+            for (int j = 0; j < k; ++j) o[((size_t)a * k + j) * cin + c] = w[((size_t)a * cin + c) * k + j];
+    return o;
+}
+
+static int load_wn_conv(wt_model* M, TensorMap& tm, const std::string& prefix, int cout, int cin, int k, ConvW* out) {
+    const float* g = tm.get(prefix + ".weight_g", cout);
+    const float* v = tm.get(prefix + ".weight_v", (int64_t)cout * cin * k);
+    const float* b = tm.get(prefix + ".bias", cout);
+    if (!g || !v || !b) return WT_ERR_MISSING_TENSOR;
+    std::vector<float> w = repack_ock(fold_wn(g, v, cout, (int64_t)cin * k), cout, cin, k);
+    out->cout = cout; out->cin = cin; out->k = k;
+    if (int rc = upload(M, w, &out->w)) return rc;
+    return upload_raw(M, b, cout, &out->b);
+}
+
+static int load_plain_conv(wt_model* M, TensorMap& tm, const std::string& prefix, int cout, int cin, int k, ConvW* out) {
+    const float* w = tm.get(prefix + ".weight", (int64_t)cout * cin * k);
+    const float* b = tm.get(prefix + ".bias", cout);
+    if (!w || !b) return WT_ERR_MISSING_TENSOR;
+    std::vector<float> wv(w, w + (int64_t)cout * cin * k);
+    std::vector<float> p = repack_ock(wv, cout, cin, k);
+    out->cout = cout; out->cin = cin; out->k = k;
+    if (int rc = upload(M, p, &out->w)) return rc;
+    return upload_raw(M, b, cout, &out->b);
+}
+
+static int load_vec(wt_model* M, TensorMap& tm, const std::string& key, int64_t n, float** out) {
+    const float* p = tm.get(key, n);
+    if (!p) return WT_ERR_MISSING_TENSOR;
+    return upload_raw(M, p, n, out);
+}
+
+// nn.LSTM weights -> packed gate order: packed row (j/4)*16 + g*4 + j%4  <-  row g*H + j
+static int load_lstm(wt_model* M, TensorMap& tm, const std::string& prefix, int H, LstmW* out, bool* split_ok) {
+    const float* wih0 = tm.get(prefix + ".lstm.weight_ih_l0", 4LL * H * H);
+    const float* whh0 = tm.get(prefix + ".lstm.weight_hh_l0", 4LL * H * H);
+    const float* bih0 = tm.get(prefix + ".lstm.bias_ih_l0", 4LL * H);
+    const float* bhh0 = tm.get(prefix + ".lstm.bias_hh_l0", 4LL * H);
+    const float* wih1 = tm.get(prefix + ".lstm.weight_ih_l1", 4LL * H * H);
+    const float* whh1 = tm.get(prefix + ".lstm.weight_hh_l1", 4LL * H * H);
+    const float* bih1 = tm.get(prefix + ".lstm.bias_ih_l1", 4LL * H);
+    const float* bhh1 = tm.get(prefix + ".lstm.bias_hh_l1", 4LL * H);
+    if (!wih0 || !whh0 || !bih0 || !bhh0 || !wih1 || !whh1 || !bih1 || !bhh1) return WT_ERR_MISSING_TENSOR;
+    std::vector<float> Wih0((size_t)4 * H * H), W0((size_t)4 * H * H), W1((size_t)4 * H * 2 * H), b0(4 * H), b1(4 * H);
+    // recurrent weights: per 16 packed gate rows (one workgroup), [K/16][64 lanes][4] with lane = lk*16 + li:
+    // element e of group S is W[row li][k = 16 S + 4 e + lk]  (the B operand of four k-steps in one 16-byte load)
+    auto put = [&](std::vector<float>& dst, size_t prow, int Ktot, int k, float v) {
+        const size_t blk = prow / 16, li = prow % 16;
+        const int S = k / 16, e = (k % 16) / 4, lk = k % 4;
+        dst[blk * 16 * Ktot + (size_t)S * 256 + (size_t)(lk * 16 + li) * 4 + e] = v;
+    };
+    // split-f16 packing: per 16 gate rows [K/32][hi, lo][64 lanes][8 halves]: half p of lane (li, lk) in block P is
+    // W[row li][k = 32 P + 16 (p >> 2) + 4 (p & 3) + lk], as hi = f16(w) and lo = f16((w - hi) * 2^11)
+    std::vector<_Float16> W0h((size_t)4 * H * H * 2), W1h((size_t)4 * H * 2 * H * 2);
+    auto put16 = [&](std::vector<_Float16>& dst, size_t prow, int Ktot, int k, float v) {
+        const size_t blk = prow / 16, li = prow % 16;
+        const int P = k / 32, r = k % 32, pp = (r / 16) * 4 + (r % 16) / 4, lk = r % 4;
+        const size_t base = blk * 16 * Ktot * 2 + (size_t)P * 1024 + (size_t)(lk * 16 + li) * 8 + pp;
+        const _Float16 h = (_Float16)v;
+        dst[base] = h;
+        dst[base + 512] = (_Float16)((v - (float)h) * 2048.f);
+    };
+    // persistent-kernel packing (H = 512): packed gate row -> (workgroup = row / 64, tile = row % 64 / 16, li = row % 16);
+    // half p of lane (li, lk) in block blk is W[row][k = 32 blk + 8 lk + p]
+    std::vector<_Float16> Wp(H == 512 ? (size_t)3 * 2048 * 512 * 2 : 0);
+    auto putp = [&](int role, size_t prow, int k, float v) {
+        if (Wp.empty()) return;
+        const size_t wg = prow / 64, tile = (prow % 64) / 16, li = prow % 16;
+        const int blk = k / 32, lk = (k % 32) / 8, pp = k % 8;
+        const size_t base = ((((size_t)role * 32 + wg) * 4 + tile) * 16 + blk) * 2 * 64 * 8 + (size_t)(lk * 16 + li) * 8 + pp;
+        const _Float16 h = (_Float16)v;
+        Wp[base] = h;
+        Wp[base + 64 * 8] = (_Float16)((v - (float)h) * 2048.f);
+    };
+    // the recurrent weights are split here, unscaled (hi = f16(w)): beyond the f16 range the model runs on fp32 kernels
+    for (const float* wsrc : {whh0, wih1, whh1})
+        for (size_t i = 0; i < (size_t)4 * H * H; ++i)
+            if (!(std::fabs(wsrc[i]) < 65504.f)) *split_ok = false;
+    for (int g = 0; g < 4; ++g)
+        for (int j = 0; j < H; ++j) {
+            const size_t src = (size_t)g * H + j;
+            const size_t dst = (size_t)(j / 4) * 16 + g * 4 + (j % 4);
+            std::memcpy(&Wih0[dst * H], &wih0[src * H], H * sizeof(float));
+            for (int k = 0; k < H; ++k) {
+                put(W0, dst, H, k, whh0[src * H + k]);
+                put(W1, dst, 2 * H, k, wih1[src * H + k]);
+                put(W1, dst, 2 * H, H + k, whh1[src * H + k]);
+                put16(W0h, dst, H, k, whh0[src * H + k]);
+                put16(W1h, dst, 2 * H, k, wih1[src * H + k]);
+                put16(W1h, dst, 2 * H, H + k, whh1[src * H + k]);
+                putp(0, dst, k, whh0[src * H + k]);
+                putp(1, dst, k, wih1[src * H + k]);
+                putp(2, dst, k, whh1[src * H + k]);
+            }
+            b0[dst] = bih0[src] + bhh0[src];
+            b1[dst] = bih1[src] + bhh1[src];
+        }
+    if (int rc = upload(M, Wih0, &out->Wih0)) return rc;
+    if (int rc = upload(M, b0, &out->b0)) return rc;
+    if (int rc = upload(M, W0, &out->W0)) return rc;
+    if (int rc = upload(M, W1, &out->W1)) return rc;
+    {
+        std::vector<float> t0(W0.size()), t1(W1.size());         // same byte counts: 2 halves per weight
+        std::memcpy(t0.data(), W0h.data(), t0.size() * sizeof(float));
+        std::memcpy(t1.data(), W1h.data(), t1.size() * sizeof(float));
+        if (int rc = upload(M, t0, &out->W0h)) return rc;
+        if (int rc = upload(M, t1, &out->W1h)) return rc;
+        if (!Wp.empty()) {
+            std::vector<float> tp(Wp.size() / 2);
+            std::memcpy(tp.data(), Wp.data(), tp.size() * sizeof(float));
+            if (int rc = upload(M, tp, &out->Wp)) return rc;
+        }
+    }
+    return upload(M, b1, &out->b1);
+}
+
+static const char* ENC = "feature_extractor.encodec.encoder.model.";
+static const char* DEC = "feature_extractor.encodec.decoder.model.";
+static const char* VQK = "feature_extractor.encodec.quantizer.vq.layers.0._codebook.";
+
+int build_model(wt_model* M, TensorMap& tm) {
+    const wt_arch& a = M->arch;
+    const int nf = 32, H = 512;
+    M->H = H;
+    // ---- encoder (encoder/modules/seanet.py:66-144)
+    {
+        const float* g = tm.get(std::string(ENC) + "0.conv.conv.weight_g", nf);
+        const float* v = tm.get(std::string(ENC) + "0.conv.conv.weight_v", (int64_t)nf * 7);
+        const float* b = tm.get(std::string(ENC) + "0.conv.conv.bias", nf);
+        if (!g || !v || !b) return WT_ERR_MISSING_TENSOR;
+        std::vector<float> w = fold_wn(g, v, nf, 7);       // [32][1][7]
+        std::vector<float> p((size_t)7 * nf);
+        for (int c = 0; c < nf; ++c)
+            for (int j = 0; j < 7; ++j) p[(size_t)j * nf + c] = w[(size_t)c * 7 + j];
+        if (int rc = upload(M, p, &M->e0_w)) return rc;
+        if (int rc = upload_raw(M, b, nf, &M->e0_b)) return rc;
+    }
+    int idx = 1, mult = 1;
+    for (int r : M->enc_ratios) {
+        ResStage st;
+        st.C = mult * nf; st.r = r;
+        const std::string p = std::string(ENC) + std::to_string(idx);
+        if (int rc = load_wn_conv(M, tm, p + ".block.1.conv.conv", st.C / 2, st.C, 3, &st.c3)) return rc;
+        if (int rc = load_wn_conv(M, tm, p + ".block.3.conv.conv", st.C, st.C / 2, 1, &st.c1)) return rc;
+        if (int rc = load_wn_conv(M, tm, p + ".shortcut.conv.conv", st.C, st.C, 1, &st.sc)) return rc;
+        if (int rc = load_wn_conv(M, tm, std::string(ENC) + std::to_string(idx + 2) + ".conv.conv", 2 * st.C, st.C, 2 * r, &st.down)) return rc;
+        M->stages.push_back(st);
+        idx += 3; mult *= 2;
+    }
+    if (mult * nf != H) { set_error("encoder width after the last ratio must be 512"); return WT_ERR_INVALID; }
+    if (int rc = load_lstm(M, tm, std::string(ENC) + std::to_string(idx), H, &M->enc_lstm, &M->s32_ok)) return rc;
+    if (int rc = load_wn_conv(M, tm, std::string(ENC) + std::to_string(idx + 2) + ".conv.conv", 512, H, 7, &M->enc_final)) return rc;
+
+    // ---- codebook (encoder/quantization/core_vq.py:122-138)
+    {
+        const float* inited = tm.get(std::string(VQK) + "inited", 1);
+        const float* e = tm.get(std::string(VQK) + "embed", (int64_t)a.vq_bins * 512);
+        if (!inited || !e) return WT_ERR_MISSING_TENSOR;
+        if (inited[0] != 1.0f) {
+            set_error("codebook buffer `inited` is not 1: the reference would run k-means on the first forward (core_vq.py:140-151)");
+            return WT_ERR_NOT_INITED;
+        }
+        if (int rc = upload_raw(M, e, (int64_t)a.vq_bins * 512, &M->embed)) return rc;
+        std::vector<float> ee(a.vq_bins);
+        for (int n = 0; n < a.vq_bins; ++n) {   // embed.pow(2).sum(0)
+            float s = 0.f;
+            for (int c = 0; c < 512; ++c) s += e[(size_t)n * 512 + c] * e[(size_t)n * 512 + c];
+            ee[n] = s;
+        }
+        if (int rc = upload(M, ee, &M->ee)) return rc;
+    }
+
+    // ---- backbone (decoder/models.py:166-216)
+    const int D = a.dim, I = a.intermediate_dim, A = a.adanorm_num_embeddings;
+    if (int rc = load_plain_conv(M, tm, "backbone.embed", D, a.input_channels, 7, &M->bb_embed)) return rc;
+    const int ridx[4] = {0, 1, 3, 4};
+    for (int i = 0; i < 4; ++i) {
+        const std::string p = "backbone.pos_net." + std::to_string(ridx[i]);
+        PosRes& r = M->res[i];
+        if (int rc = load_vec(M, tm, p + ".norm1.weight", D, &r.n1w)) return rc;
+        if (int rc = load_vec(M, tm, p + ".norm1.bias", D, &r.n1b)) return rc;
+        if (int rc = load_vec(M, tm, p + ".norm2.weight", D, &r.n2w)) return rc;
+        if (int rc = load_vec(M, tm, p + ".norm2.bias", D, &r.n2b)) return rc;
+        if (int rc = load_plain_conv(M, tm, p + ".conv1", D, D, 3, &r.c1)) return rc;
+        if (int rc = load_plain_conv(M, tm, p + ".conv2", D, D, 3, &r.c2)) return rc;
+    }
+    {
+        const std::string p = "backbone.pos_net.2";
+        if (int rc = load_vec(M, tm, p + ".norm.weight", D, &M->at_nw)) return rc;
+        if (int rc = load_vec(M, tm, p + ".norm.bias", D, &M->at_nb)) return rc;
+        const float* wq = tm.get(p + ".q.weight", (int64_t)D * D);
+        const float* wk = tm.get(p + ".k.weight", (int64_t)D * D);
+        const float* bq = tm.get(p + ".q.bias", D);
+        const float* bk = tm.get(p + ".k.bias", D);
+        if (!wq || !wk || !bq || !bk) return WT_ERR_MISSING_TENSOR;
+        std::vector<float> wqk((size_t)2 * D * D), bqk(2 * D);
+        std::memcpy(&wqk[0], wq, (size_t)D * D * sizeof(float));
+        std::memcpy(&wqk[(size_t)D * D], wk, (size_t)D * D * sizeof(float));
+        std::memcpy(&bqk[0], bq, D * sizeof(float));
+        std::memcpy(&bqk[D], bk, D * sizeof(float));
+        if (int rc = upload(M, wqk, &M->at_Wqk)) return rc;
+        if (int rc = upload(M, bqk, &M->at_bqk)) return rc;
+        if (int rc = load_vec(M, tm, p + ".v.weight", (int64_t)D * D, &M->at_Wv)) return rc;
+        if (int rc = load_vec(M, tm, p + ".v.bias", D, &M->at_bv)) return rc;
+        if (int rc = load_vec(M, tm, p + ".proj_out.weight", (int64_t)D * D, &M->at_Wp)) return rc;
+        if (int rc = load_vec(M, tm, p + ".proj_out.bias", D, &M->at_bp)) return rc;
+    }
+    if (int rc = load_vec(M, tm, "backbone.pos_net.5.weight", D, &M->gn5w)) return rc;
+    if (int rc = load_vec(M, tm, "backbone.pos_net.5.bias", D, &M->gn5b)) return rc;
+    if (A <= 0) { set_error("only the AdaLayerNorm (adanorm_num_embeddings > 0) backbone is implemented"); return WT_ERR_INVALID; }
+    if (int rc = load_vec(M, tm, "backbone.norm.scale.weight", (int64_t)A * D, &M->ada_s)) return rc;
+    if (int rc = load_vec(M, tm, "backbone.norm.shift.weight", (int64_t)A * D, &M->ada_h)) return rc;
+    for (int i = 0; i < a.num_layers; ++i) {
+        const std::string p = "backbone.convnext." + std::to_string(i);
+        CnxBlock c;
+        const float* dw = tm.get(p + ".dwconv.weight", (int64_t)D * 7);
+        if (!dw) return WT_ERR_MISSING_TENSOR;
+        std::vector<float> dwp((size_t)7 * D);
+        for (int ch = 0; ch < D; ++ch)
+            for (int j = 0; j < 7; ++j) dwp[(size_t)j * D + ch] = dw[(size_t)ch * 7 + j];
+        if (int rc = upload(M, dwp, &c.dw_w)) return rc;
+        if (int rc = load_vec(M, tm, p + ".dwconv.bias", D, &c.dw_b)) return rc;
+        if (int rc = load_vec(M, tm, p + ".norm.scale.weight", (int64_t)A * D, &c.ada_s)) return rc;
+        if (int rc = load_vec(M, tm, p + ".norm.shift.weight", (int64_t)A * D, &c.ada_h)) return rc;
+        if (int rc = load_vec(M, tm, p + ".pwconv1.weight", (int64_t)I * D, &c.W1)) return rc;
+        if (int rc = load_vec(M, tm, p + ".pwconv1.bias", I, &c.b1)) return rc;
+        if (int rc = load_vec(M, tm, p + ".pwconv2.weight", (int64_t)D * I, &c.W2)) return rc;
+        if (int rc = load_vec(M, tm, p + ".pwconv2.bias", D, &c.b2)) return rc;
+        if (int rc = load_vec(M, tm, p + ".gamma", D, &c.gamma)) return rc;
+        M->cnx.push_back(c);
+    }
+    if (int rc = load_vec(M, tm, "backbone.final_layer_norm.weight", D, &M->fln_w)) return rc;
+    if (int rc = load_vec(M, tm, "backbone.final_layer_norm.bias", D, &M->fln_b)) return rc;
+
+    // ---- head (decoder/heads.py:36-67, decoder/spectral_ops.py:33-75)
+    {
+        const int N = a.n_fft, hop = a.hop_length;
+        if (N % hop != 0 || N % 2 != 0 || (N - hop) % 2 != 0) {
+            set_error("ISTFT kernel needs n_fft to be an even multiple of hop_length"); return WT_ERR_INVALID;
+        }
+        if (N % 4 != 0) { set_error("ISTFT kernel needs n_fft % 4 == 0"); return WT_ERR_INVALID; }
+        const int bins = N / 2 + 1;
+        const int Q = N / 4;
+        const int Kq = ((Q + 1 + 31) / 32) * 32;          // padded count of even (Q+1) / odd (Q) bins
+        const int Kb = 2 * Kq;                            // spectrum half-row: [even bins | odd bins]
+        const int R = N / hop;
+        M->Kb = Kb; M->Kq = Kq; M->bins_f = bins; M->R = R;
+        const float* w = tm.get("head.out.weight", (int64_t)(N + 2) * D);
+        const float* b = tm.get("head.out.bias", N + 2);
+        const float* win = tm.get("head.istft.window", N);
+        if (!w || !b || !win) return WT_ERR_MISSING_TENSOR;
+        // spectrum slot s -> frequency bin: s < Kq: even bin 2s; else odd bin 2(s-Kq)+1 (-1 = padding)
+        auto slot_bin = [&](int s) { int f = s < Kq ? 2 * s : 2 * (s - Kq) + 1; return f <= N / 2 && (s < Kq || s - Kq < Q) ? f : -1; };
+        // packed head rows: 64-row groups = 32 log-magnitude rows then the 32 phase rows of the same slots
+        std::vector<float> wp((size_t)2 * Kb * D, 0.f), bp((size_t)2 * Kb, 0.f);
+        for (int sl = 0; sl < Kb; ++sl) {
+            const int f = slot_bin(sl);
+            if (f < 0) continue;
+            const size_t pm = (size_t)(sl / 32) * 64 + (sl % 32), pp = pm + 32;
+            std::memcpy(&wp[pm * D], &w[(size_t)f * D], D * sizeof(float));
+            std::memcpy(&wp[pp * D], &w[(size_t)(bins + f) * D], D * sizeof(float));
+            bp[pm] = b[f];
+            bp[pp] = b[bins + f];
+        }
+        if (int rc = upload(M, wp, &M->head_W)) return rc;
+        if (int rc = upload(M, bp, &M->head_b)) return rc;
+        // Inverse real DFT, two radix-2 splits then dense: with theta = 2 pi f n / N,
+        //   x[n] = C[n] - S[n], x[N-n] = C[n] + S[n]            (n <= N/2;  C = sum c_f Re cos, S = sum c_f Im sin, /N)
+        //   C[n] = Ce[n] + Co[n], C[N/2-n] = Ce[n] - Co[n]      (n <= N/4;  even / odd bins)
+        //   S[n] = Se[n] + So[n], S[N/2-n] = So[n] - Se[n]
+        // so four (N/4+1) x (N/4+1) bases replace the N x (N/2+1) complex one: 1/4 of the multiply-adds.
+        std::vector<float> basis((size_t)4 * Kq * Kq, 0.f);
+        const double two_pi = 6.283185307179586476925286766559;
+        for (int n = 0; n <= Q; ++n)
+            for (int g = 0; g <= Q; ++g) {
+                const int fe = 2 * g, fo = 2 * g + 1;
+                const bool edge = (fe == 0) || (fe == N / 2);
+                const double ce = (edge ? 1.0 : 2.0) / (double)N, co = 2.0 / (double)N;
+                const double the = two_pi * (double)(((long)fe * n) % N) / (double)N;
+                const double tho = two_pi * (double)(((long)fo * n) % N) / (double)N;
+                basis[((size_t)0 * Kq + n) * Kq + g] = (float)(ce * std::cos(the));
+                basis[((size_t)2 * Kq + n) * Kq + g] = edge ? 0.f : (float)(ce * std::sin(the));   // C2R ignores Im of DC/Nyquist
+                if (g < Q) {
+                    basis[((size_t)1 * Kq + n) * Kq + g] = (float)(co * std::cos(tho));
+                    basis[((size_t)3 * Kq + n) * Kq + g] = (float)(co * std::sin(tho));
+                }
+            }
+        if (int rc = upload(M, basis, &M->istft_W)) return rc;
+        if (int rc = upload_raw(M, win, N, &M->win)) return rc;
+        std::vector<float> wsq(N);
+        for (int n = 0; n < N; ++n) wsq[n] = win[n] * win[n];
+        if (int rc = upload(M, wsq, &M->wsq)) return rc;
+    }
+
+    // ---- optional SEANetDecoder (encoder/modules/seanet.py:147-238)
+    M->has_seadec = tm.has(std::string(DEC) + "0.conv.conv.weight_v");
+    if (M->has_seadec) {
+        int m2 = 1 << a.n_ratios;
+        if (int rc = load_wn_conv(M, tm, std::string(DEC) + "0.conv.conv", m2 * nf, 512, 7, &M->sd_first)) return rc;
+        if (int rc = load_lstm(M, tm, std::string(DEC) + "1", H, &M->sd_lstm, &M->sd_s32_ok)) return rc;
+        int di = 2;
+        for (int i = 0; i < a.n_ratios; ++i) {
+            const int r = a.ratios[i];
+            SeaDecStage st;
+            st.cin = m2 * nf; st.cout = st.cin / 2; st.k = 2 * r; st.r = r;
+            const std::string p = std::string(DEC) + std::to_string(di + 1) + ".convtr.convtr";
+            const float* g = tm.get(p + ".weight_g", st.cin);
+            const float* v = tm.get(p + ".weight_v", (int64_t)st.cin * st.cout * st.k);
+            const float* b = tm.get(p + ".bias", st.cout);
+            if (!g || !v || !b) return WT_ERR_MISSING_TENSOR;
+            std::vector<float> w = fold_wn(g, v, st.cin, (int64_t)st.cout * st.k);   // [cin][cout][k], g per cin
+            std::vector<float> pk((size_t)st.k * st.cin * st.cout);
+            for (int ci = 0; ci < st.cin; ++ci)
+                for (int co = 0; co < st.cout; ++co)
+                    for (int j = 0; j < st.k; ++j)
+                        pk[((size_t)j * st.cin + ci) * st.cout + co] = w[((size_t)ci * st.cout + co) * st.k + j];
+            if (int rc = upload(M, pk, &st.tr_w)) return rc;
+            if (st.k == 2 * r) {      // every output sample has exactly two contributing frames -> one GEMM per phase
+                std::vector<float> pp((size_t)r * st.cout * 2 * st.cin);
+                for (int ph = 0; ph < r; ++ph)
+                    for (int co = 0; co < st.cout; ++co)
+                        for (int ci = 0; ci < st.cin; ++ci) {
+                            pp[(((size_t)ph * st.cout + co) * 2 + 0) * st.cin + ci] = w[((size_t)ci * st.cout + co) * st.k + ph + r];
+                            pp[(((size_t)ph * st.cout + co) * 2 + 1) * st.cin + ci] = w[((size_t)ci * st.cout + co) * st.k + ph];
+                        }
+                if (int rc = upload(M, pp, &st.tr_wp)) return rc;
+            }
+            if (int rc = upload_raw(M, b, st.cout, &st.tr_b)) return rc;
+            const std::string rp = std::string(DEC) + std::to_string(di + 2);
+            const int h = st.cout;
+            if (int rc = load_wn_conv(M, tm, rp + ".block.1.conv.conv", h / 2, h, 3, &st.c3)) return rc;
+            if (int rc = load_wn_conv(M, tm, rp + ".block.3.conv.conv", h, h / 2, 1, &st.c1)) return rc;
+            if (int rc = load_wn_conv(M, tm, rp + ".shortcut.conv.conv", h, h, 1, &st.sc)) return rc;
+            M->sd_stages.push_back(st);
+            di += 3; m2 /= 2;
+        }
+        const std::string p = std::string(DEC) + std::to_string(di + 1) + ".conv.conv";
+        const float* g = tm.get(p + ".weight_g", 1);
+        const float* v = tm.get(p + ".weight_v", (int64_t)nf * 7);
+        const float* b = tm.get(p + ".bias", 1);
+        if (!g || !v || !b) return WT_ERR_MISSING_TENSOR;
+        std::vector<float> w = fold_wn(g, v, 1, (int64_t)nf * 7);   // [1][32][7]
+        std::vector<float> pk((size_t)7 * nf);
+        for (int c = 0; c < nf; ++c)
+            for (int j = 0; j < 7; ++j) pk[(size_t)j * nf + c] = w[(size_t)c * 7 + j];
+        if (int rc = upload(M, pk, &M->sd_last_w)) return rc;
+        if (int rc = upload_raw(M, b, 1, &M->sd_last_b)) return rc;
+    }
+    return 0;
+}
+
+static int add_split(wt_model* M, const float* w, long n) {
+    if (!w || n <= 0 || (n % 8)) return 0;
+    void* d = nullptr;
+    WT_HIP_CHECK(hipMalloc(&d, (size_t)n * 4));
+    M->allocs.push_back(d);
+    M->weight_bytes += n * 4;
+    if (int rc = launch_split_f16x2(w, d, static_cast<char*>(d) + (size_t)n * 2, n, nullptr)) return rc;
+    M->split16[w] = {d, n};
+    return 0;
+}
+
+// S32 copy of a GEMM weight.  hi = f16(w) covers |w| < 65504 with fp32-equivalent products only while the tensor's
+// largest magnitude is not far from 1 (x = hi + lo * 2^-11 has an absolute floor of 2^-36), so a tensor whose maximum
+// lies outside [2^-6, 2^12] is stored as w * 2^e (maximum brought into [1, 2)) and its GEMMs multiply their
+// accumulators by 2^-e (GemmArgs::acc_scale; powers of two: exact).  A non-finite weight cannot be split at all:
+// the model then runs on the fp32 MFMA chain (wt_model::s32_ok).
+static int add_s32(wt_model* M, const float* w, long n, bool* split_ok = nullptr) {
+    if (!w || n <= 0 || (n % 32)) return 0;
+    if (!split_ok) split_ok = &M->s32_ok;
+    std::vector<float> h((size_t)n);
+    WT_HIP_CHECK(hipMemcpy(h.data(), w, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    float amax = 0.f;
+    bool finite = true;
+    for (long i = 0; i < n; ++i) {
+        const float v = std::fabs(h[i]);
+        if (!(v <= 3.0e38f)) finite = false;
+        else amax = std::max(amax, v);
+    }
+    if (!finite) *split_ok = false;
+    M->w_amax = std::max(M->w_amax, amax);
+    float scale = 1.f;
+    if (finite && amax > 0.f && (amax < 0x1p-6f || amax >= 0x1p12f)) {
+        int e = 0;
+        (void)std::frexp(amax, &e);                 // amax = m * 2^e, m in [0.5, 1)
+        scale = std::ldexp(1.f, 1 - e);             // amax * scale in [1, 2)
+    }
+    float* scale_dev = nullptr;
+    if (scale != 1.f) {
+        if (int rc = upload(M, std::vector<float>{scale}, &scale_dev)) return rc;
+        M->s32_acc_scale[w] = 1.f / scale;
+    }
+    void* d = nullptr;
+    WT_HIP_CHECK(hipMalloc(&d, (size_t)n * 4));
+    M->allocs.push_back(d);
+    M->weight_bytes += n * 4;
+    if (int rc = launch_split_s32(w, d, n, nullptr, scale_dev)) return rc;
+    M->s32[w] = d;
+    return 0;
+}
+
+int build_splits(wt_model* M) {
+    const wt_arch& a = M->arch;
+    const int D = a.dim, I = a.intermediate_dim;
+    auto conv = [&](const ConvW& c) { return add_split(M, c.w, (long)c.cout * c.k * c.cin); };
+    auto conv32 = [&](const ConvW& c) { return (c.cin % 32) ? 0 : add_s32(M, c.w, (long)c.cout * c.k * c.cin); };
+    // the SEANetDecoder's weights are all zeros -> NaN after the weight-norm fold when a checkpoint without them was
+    // loaded into the full module tree: they only decide how the SEANetDecoder plan runs
+    auto conv32sd = [&](const ConvW& c) { return (c.cin % 32) ? 0 : add_s32(M, c.w, (long)c.cout * c.k * c.cin, &M->sd_s32_ok); };
+    for (const ResStage& st : M->stages) {      // encoder chain on S32 operands (build_encode)
+        if (st.down.cin % 32 == 0 && st.down.k == 2 * st.r && st.down.k <= 32) {
+            // k = 2 * stride: every input frame feeds two output frames (taps j and j + stride).  Packing the taps as
+            // (0, r, 1, r+1, ...) puts those two reads in adjacent K steps
+            const long n = (long)st.down.cout * st.down.k * st.down.cin;
+            std::vector<float> h((size_t)n), pk((size_t)n);
+            WT_HIP_CHECK(hipMemcpy(h.data(), st.down.w, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+            for (int co = 0; co < st.down.cout; ++co)
+                for (int q = 0; q < st.down.k; ++q) {
+                    const int tap = (q >> 1) + (q & 1) * st.r;
+                    std::memcpy(&pk[((size_t)co * st.down.k + q) * st.down.cin], &h[((size_t)co * st.down.k + tap) * st.down.cin],
+                                st.down.cin * sizeof(float));
+                }
+            float* dpk = nullptr;
+            if (int rc = upload(M, pk, &dpk)) return rc;
+            if (int rc = add_s32(M, dpk, n)) return rc;
+            M->s32[st.down.w] = M->s32.at(dpk);
+            if (M->s32_acc_scale.count(dpk)) M->s32_acc_scale[st.down.w] = M->s32_acc_scale.at(dpk);
+            M->s32_tap_pair[st.down.w] = true;
+        } else
+        if (int rc = conv32(st.down)) return rc;
+        if (int rc = conv32(st.c3)) return rc;
+        if (int rc = conv32(st.c1)) return rc;
+        if (int rc = conv32(st.sc)) return rc;
+    }
+    if (int rc = add_s32(M, M->enc_lstm.Wih0, 4L * M->H * M->H)) return rc;
+    if (int rc = conv32(M->enc_final)) return rc;
+    if (int rc = add_s32(M, M->embed, (long)a.vq_bins * 512)) return rc;
+    if (int rc = conv32(M->bb_embed)) return rc;
+    for (int i = 0; i < 4; ++i) {
+        if (int rc = conv32(M->res[i].c1)) return rc;
+        if (int rc = conv32(M->res[i].c2)) return rc;
+    }
+    for (const CnxBlock& c : M->cnx) {
+        if (int rc = add_s32(M, c.W1, (long)I * D)) return rc;
+        if (int rc = add_s32(M, c.W2, (long)D * I)) return rc;
+    }
+    if (int rc = add_s32(M, M->head_W, 2L * M->Kb * D)) return rc;
+    if (int rc = add_s32(M, M->istft_W, 4L * M->Kq * M->Kq)) return rc;
+    if (int rc = add_s32(M, M->at_Wqk, 2L * D * D)) return rc;
+    if (int rc = add_s32(M, M->at_Wv, (long)D * D)) return rc;
+    if (int rc = add_s32(M, M->at_Wp, (long)D * D)) return rc;
+    if (M->has_seadec) {
+        if (int rc = conv32sd(M->sd_first)) return rc;
+        if (int rc = add_s32(M, M->sd_lstm.Wih0, 4L * M->H * M->H, &M->sd_s32_ok)) return rc;
+        for (const SeaDecStage& st : M->sd_stages) {
+            if (st.tr_wp && st.cin % 16 == 0) if (int rc = add_s32(M, st.tr_wp, (long)st.r * st.cout * 2 * st.cin, &M->sd_s32_ok)) return rc;
+            if (resblock_fusable(st.cout)) continue;            // its convs run inside resblock16
+            if (int rc = conv32sd(st.sc)) return rc;
+            if (int rc = conv32sd(st.c3)) return rc;
+            if (int rc = conv32sd(st.c1)) return rc;
+        }
+    }
+    for (const ResStage& st : M->stages) {
+        if (int rc = conv(st.down)) return rc;
+        if (int rc = conv(st.sc)) return rc;
+        if (int rc = conv(st.c3)) return rc;
+        if (int rc = conv(st.c1)) return rc;
+    }
+    if (int rc = add_split(M, M->embed, (long)a.vq_bins * 512)) return rc;
+    if (int rc = add_split(M, M->head_W, 2L * M->Kb * D)) return rc;
+    if (int rc = conv(M->enc_final)) return rc;
+    if (int rc = add_split(M, M->enc_lstm.Wih0, 4L * M->H * M->H)) return rc;
+    if (int rc = conv(M->bb_embed)) return rc;
+    for (int i = 0; i < 4; ++i) {
+        if (int rc = conv(M->res[i].c1)) return rc;
+        if (int rc = conv(M->res[i].c2)) return rc;
+    }
+    if (int rc = add_split(M, M->at_Wqk, 2L * D * D)) return rc;
+    if (int rc = add_split(M, M->at_Wp, (long)D * D)) return rc;
+    for (const CnxBlock& c : M->cnx) {
+        if (int rc = add_split(M, c.W1, (long)I * D)) return rc;
+        if (int rc = add_split(M, c.W2, (long)D * I)) return rc;
+    }
+    if (int rc = add_split(M, M->istft_W, 4L * M->Kq * M->Kq)) return rc;
+    if (M->has_seadec) {
+        if (int rc = conv(M->sd_first)) return rc;
+        if (int rc = add_split(M, M->sd_lstm.Wih0, 4L * M->H * M->H)) return rc;
+        for (const SeaDecStage& st : M->sd_stages) {
+            if (st.tr_wp) if (int rc = add_split(M, st.tr_wp, (long)st.r * st.cout * 2 * st.cin)) return rc;
+            if (int rc = conv(st.sc)) return rc;
+            if (int rc = conv(st.c3)) return rc;
+            if (int rc = conv(st.c1)) return rc;
+        }
+    }
+    WT_HIP_CHECK(hipDeviceSynchronize());
+    return 0;
+}
+
+}  // namespace wt

@@ -98,7 +98,7 @@ class EncodecFeatures(_Holder):
 
     @torch.inference_mode()
     def infer(self, audio: torch.Tensor, bandwidth_id: torch.Tensor):
-        _ = self.bandwidths[int(bandwidth_id.reshape(-1)[0])] if bandwidth_id is not None else None
+        _ = self.bandwidths[self._root()._bandwidth_index(bandwidth_id)] if bandwidth_id is not None else None
         feats, codes, _emb = self._root()._run_encode(audio, want_emb=False)
         commit_loss = torch.zeros((), device=audio.device)
         return feats, codes, commit_loss
@@ -152,6 +152,7 @@ class _Engine:
 
     def __init__(self):
         self.model = ctypes.c_void_p()
+        self.max_plans = int(os.environ.get("WAVTOK_MAX_PLANS", "8"))
         self.plans: Dict[Tuple[int, int, int, int], Tuple[ctypes.c_void_p, torch.Tensor]] = {}
         self.io: Dict[Tuple[int, int, int, int], Dict[str, torch.Tensor]] = {}     # fixed I/O buffers of graph plans
         self.device_index = -1
@@ -197,10 +198,11 @@ class _Engine:
 
     def plan(self, kind: int, B: int, length: int, flags: int, device: torch.device):
         key = (kind, B, length, flags)
-        hit = self.plans.get(key)
+        hit = self.plans.pop(key, None)
         if hit is not None:
+            self.plans[key] = hit                     # most recently used last (dicts keep insertion order)
             return hit
-        if len(self.plans) >= 8:                      # small LRU: drop the oldest plan + workspace
+        if len(self.plans) >= self.max_plans:         # LRU: drop the least recently used plan + workspace
             old = next(iter(self.plans))
             lib.wt_plan_destroy(self.plans.pop(old)[0])
             self.io.pop(old, None)
@@ -209,6 +211,12 @@ class _Engine:
         ws = torch.empty(lib.wt_plan_workspace_bytes(p), dtype=torch.uint8, device=device)
         self.plans[key] = (p, ws)
         return p, ws
+
+    def drop(self, pred):
+        """Destroys the cached plans (and their workspaces) whose key (kind, B, length, flags) satisfies pred."""
+        for k in [k for k in self.plans if pred(k)]:
+            lib.wt_plan_destroy(self.plans.pop(k)[0])
+            self.io.pop(k, None)
 
     def staging(self, kind: int, B: int, length: int, flags: int, make) -> Dict[str, torch.Tensor]:
         """Fixed input/output tensors of a graph plan: a recorded hipGraph replays fixed addresses, so calls copy their
@@ -242,6 +250,9 @@ class WavTokenizer(nn.Module):
         self._engine = _Engine()
         self._dirty = True
         self._plan_flags = 0
+        self._strict = os.environ.get("WAVTOK_STRICT_STATUS", "0") == "1"
+        self._check_codes = os.environ.get("WAVTOK_CHECK_CODES", "1") == "1"   # codes_to_features raises on bad indices
+        self._bw_cache = None                # (tensor ref, version, index): bandwidth_id tensors living on the GPU
         # batches up to this many clips are replayed as one hipGraph per (shape) plan: they are bound by the host's
         # launch rate (about 100 launches per call), not by the GPU; 0 turns graphs off
         self._graph_max_clips = int(os.environ.get("WAVTOK_GRAPH_MAX_CLIPS", "16"))
@@ -356,10 +367,38 @@ class WavTokenizer(nn.Module):
         """Call after mutating parameters in place."""
         self._dirty = True
 
-    def set_debug_keep_stages(self, on: bool):
-        """Parity tests: keep every stage buffer of the next plans distinct in the workspace."""
-        self._plan_flags = (self._plan_flags | _capi.WT_PLAN_FLAG_KEEP_STAGES) if on else \
-            (self._plan_flags & ~_capi.WT_PLAN_FLAG_KEEP_STAGES)
+    def set_debug_keep_stages(self, on: bool, unfused: bool = False):
+        """Parity tests: keep every stage buffer of the next plans distinct in the workspace (and snapshot the in-place
+        residual stream).  The kernels stay the shipped ones; `unfused=True` selects the unfused debug twin instead
+        (raw fp32 tensors between stages)."""
+        f = self._plan_flags & ~(_capi.WT_PLAN_FLAG_KEEP_STAGES | _capi.WT_PLAN_FLAG_UNFUSED)
+        if on:
+            f |= _capi.WT_PLAN_FLAG_KEEP_STAGES | (_capi.WT_PLAN_FLAG_UNFUSED if unfused else 0)
+        self._plan_flags = f
+
+    def set_strict_status(self, on: bool):
+        """Device-side failures of a call (an activation beyond the f16 range of the split-f16 form; a persistent-LSTM step
+        barrier that timed out) always overwrite that call's outputs (codes = -1, NaN) and surface as an error on the
+        NEXT call on the same plan, which this class answers by falling back (fp32 GEMMs / launch-per-step LSTM) and
+        running that next call.  strict=True additionally synchronises after every call, checks, falls back and REPEATS
+        the failed call itself, so no poisoned result is ever handed out (costs the host/GPU overlap between calls)."""
+        self._strict = bool(on)
+
+    def check_status(self):
+        """Synchronise and raise WavTokError if any call since the last check failed on the device."""
+        dev = self._device()
+        torch.cuda.current_stream(dev).synchronize()
+        bad = []
+        for key, (plan, _ws) in self._engine.plans.items():
+            bits = ctypes.c_int32()
+            check(lib.wt_plan_status(plan, ctypes.byref(bits), 1), "wt_plan_status")
+            if bits.value:
+                bad.append((key, bits.value))
+                if bits.value & _capi.WT_STATUS_BIT_RANGE:
+                    self._plan_flags |= _capi.WT_PLAN_FLAG_FP32_GEMM
+        if bad:
+            raise WavTokError("device-side failure in earlier calls (plan key, status bits): %s; their outputs were "
+                              "overwritten with -1 / NaN; later calls fall back (fp32 GEMMs / step LSTM)" % bad)
 
     def set_gemm_precision(self, mode: str):
         """"f16x3" (default): dense layers on the fp32-equivalent split-f16 MFMA kernel; "f32": the plain
@@ -377,6 +416,31 @@ class WavTokenizer(nn.Module):
         if 0 < B <= self._graph_max_clips and not (self._plan_flags & _capi.WT_PLAN_FLAG_KEEP_STAGES):
             return self._plan_flags | _capi.WT_PLAN_FLAG_GRAPH
         return self._plan_flags
+
+    def _guarded(self, dev: torch.device, get_plan, launch):
+        """Runs launch(plan, ws) with the fallbacks for device-side failures (set_strict_status).  get_plan() builds the
+        plan from the CURRENT flags, so a fallback that changes them re-plans."""
+        for attempt in range(3):
+            plan, ws = get_plan()
+            try:
+                out = launch(plan, ws)
+            except WavTokError as e:
+                if e.status == _capi.WT_ERR_LSTM_SYNC and attempt < 2:
+                    continue                                  # the plan now runs the step LSTM
+                if e.status == _capi.WT_ERR_RANGE and attempt < 2:
+                    self._plan_flags |= _capi.WT_PLAN_FLAG_FP32_GEMM
+                    continue
+                raise
+            if not self._strict:
+                return out
+            torch.cuda.current_stream(dev).synchronize()
+            bits = ctypes.c_int32()
+            check(lib.wt_plan_status(plan, ctypes.byref(bits), 1), "wt_plan_status")
+            if not bits.value:
+                return out
+            if bits.value & _capi.WT_STATUS_BIT_RANGE:
+                self._plan_flags |= _capi.WT_PLAN_FLAG_FP32_GEMM
+        raise WavTokError("the call kept failing on the device after the fp32 / step-LSTM fallbacks")
 
     def set_lstm_mode(self, mode: str):
         """"persistent" (default): the whole LSTM recurrence in one launch (per-XCD clip groups, weights resident);
@@ -420,25 +484,28 @@ class WavTokenizer(nn.Module):
         assert audio.dim() == 2, "expected audio of shape (B, T)"
         audio = self._as_input(audio, dev)
         B, T = audio.shape
-        flags = self._graph_flags(B)
-        plan, ws = self._engine.plan(_capi.WT_PLAN_ENCODE, B, T, flags, dev)
-        L = int(lib.wt_plan_frames(plan))
-        if flags & _capi.WT_PLAN_FLAG_GRAPH:
-            io = self._engine.staging(_capi.WT_PLAN_ENCODE, B, T, flags, lambda: {
-                "in": torch.empty((B, T), dtype=torch.float32, device=dev),
-                "feats": torch.empty((B, 512, L), dtype=torch.float32, device=dev),
-                "codes": torch.empty((1, B, L), dtype=torch.int64, device=dev),
-                "emb": torch.empty((B, 512, L), dtype=torch.float32, device=dev)})
-            io["in"].copy_(audio)
-            check(lib.wt_encode(plan, _ptr(io["in"]), _ptr(io["feats"]), _ptr(io["codes"]), _ptr(io["emb"]), _ptr(ws),
-                                _stream_ptr(dev)), "wt_encode")
-            return io["feats"].clone(), io["codes"].clone(), (io["emb"].clone() if want_emb else None)
-        feats = torch.empty((B, 512, L), dtype=torch.float32, device=dev)
-        codes = torch.empty((1, B, L), dtype=torch.int64, device=dev)
-        emb = torch.empty((B, 512, L), dtype=torch.float32, device=dev) if want_emb else None
-        check(lib.wt_encode(plan, _ptr(audio), _ptr(feats), _ptr(codes), _ptr(emb), _ptr(ws), _stream_ptr(dev)),
-              "wt_encode")
-        return feats, codes, emb
+        L = self._arch.frames(T)
+
+        def launch(plan, ws):
+            flags = self._graph_flags(B)
+            if flags & _capi.WT_PLAN_FLAG_GRAPH:
+                io = self._engine.staging(_capi.WT_PLAN_ENCODE, B, T, flags, lambda: {
+                    "in": torch.empty((B, T), dtype=torch.float32, device=dev),
+                    "feats": torch.empty((B, 512, L), dtype=torch.float32, device=dev),
+                    "codes": torch.empty((1, B, L), dtype=torch.int64, device=dev),
+                    "emb": torch.empty((B, 512, L), dtype=torch.float32, device=dev)})
+                io["in"].copy_(audio)
+                check(lib.wt_encode(plan, _ptr(io["in"]), _ptr(io["feats"]), _ptr(io["codes"]), _ptr(io["emb"]), _ptr(ws),
+                                    _stream_ptr(dev)), "wt_encode")
+                return io["feats"].clone(), io["codes"].clone(), (io["emb"].clone() if want_emb else None)
+            feats = torch.empty((B, 512, L), dtype=torch.float32, device=dev)
+            codes = torch.empty((1, B, L), dtype=torch.int64, device=dev)
+            emb = torch.empty((B, 512, L), dtype=torch.float32, device=dev) if want_emb else None
+            check(lib.wt_encode(plan, _ptr(audio), _ptr(feats), _ptr(codes), _ptr(emb), _ptr(ws), _stream_ptr(dev)),
+                  "wt_encode")
+            return feats, codes, emb
+
+        return self._guarded(dev, lambda: self._engine.plan(_capi.WT_PLAN_ENCODE, B, T, self._graph_flags(B), dev), launch)
 
     def _bandwidth_index(self, bandwidth_id) -> int:
         if bandwidth_id is None:
@@ -446,7 +513,16 @@ class WavTokenizer(nn.Module):
         if isinstance(bandwidth_id, torch.Tensor):
             if bandwidth_id.numel() != 1:
                 raise ValueError("bandwidth_id must hold one index (the reference broadcasts a (1, dim) embedding row)")
-            return int(bandwidth_id.reshape(-1)[0])
+            if bandwidth_id.device.type == "cpu":
+                return int(bandwidth_id.reshape(-1)[0])
+            # a tensor on the GPU (infer.py:52 builds it there once and passes it to every call): reading it is a
+            # device synchronisation, so the value is remembered per tensor object and version
+            c = self._bw_cache
+            if c is not None and c[0]() is bandwidth_id and c[1] == bandwidth_id._version:
+                return c[2]
+            v = int(bandwidth_id.reshape(-1)[0])
+            self._bw_cache = (weakref.ref(bandwidth_id), bandwidth_id._version, v)
+            return v
         return int(bandwidth_id)
 
     def _run_decode(self, features: torch.Tensor, bandwidth_id, want_backbone: bool = False):
@@ -455,45 +531,72 @@ class WavTokenizer(nn.Module):
         bw = self._bandwidth_index(bandwidth_id)
         features = self._as_input(features, dev)
         B, _, L = features.shape
-        flags = self._graph_flags(B) if not want_backbone else self._plan_flags
-        plan, ws = self._engine.plan(_capi.WT_PLAN_DECODE, B, L, flags, dev)
-        if flags & _capi.WT_PLAN_FLAG_GRAPH:
-            io = self._engine.staging(_capi.WT_PLAN_DECODE, B, L, flags, lambda: {
-                "in": torch.empty((B, self._arch.input_channels, L), dtype=torch.float32, device=dev),
-                "wav": torch.empty((B, L * self._arch.hop_length), dtype=torch.float32, device=dev)})
-            io["in"].copy_(features)
-            check(lib.wt_decode(plan, _ptr(io["in"]), bw, _ptr(io["wav"]), _ptr(None), _ptr(ws), _stream_ptr(dev)), "wt_decode")
-            return io["wav"].clone(), None
-        wav = torch.empty((B, L * self._arch.hop_length), dtype=torch.float32, device=dev)
-        bb = torch.empty((B, L, self._arch.dim), dtype=torch.float32, device=dev) if want_backbone else None
-        check(lib.wt_decode(plan, _ptr(features), bw, _ptr(wav), _ptr(bb), _ptr(ws), _stream_ptr(dev)), "wt_decode")
-        return wav, bb
+        cur_flags = lambda: self._graph_flags(B) if not want_backbone else self._plan_flags
+
+        def launch(plan, ws):
+            flags = cur_flags()
+            if flags & _capi.WT_PLAN_FLAG_GRAPH:
+                io = self._engine.staging(_capi.WT_PLAN_DECODE, B, L, flags, lambda: {
+                    "in": torch.empty((B, self._arch.input_channels, L), dtype=torch.float32, device=dev),
+                    "wav": torch.empty((B, L * self._arch.hop_length), dtype=torch.float32, device=dev)})
+                io["in"].copy_(features)
+                check(lib.wt_decode(plan, _ptr(io["in"]), bw, _ptr(io["wav"]), _ptr(None), _ptr(ws), _stream_ptr(dev)), "wt_decode")
+                return io["wav"].clone(), None
+            wav = torch.empty((B, L * self._arch.hop_length), dtype=torch.float32, device=dev)
+            bb = torch.empty((B, L, self._arch.dim), dtype=torch.float32, device=dev) if want_backbone else None
+            check(lib.wt_decode(plan, _ptr(features), bw, _ptr(wav), _ptr(bb), _ptr(ws), _stream_ptr(dev)), "wt_decode")
+            return wav, bb
+
+        return self._guarded(dev, lambda: self._engine.plan(_capi.WT_PLAN_DECODE, B, L, cur_flags(), dev), launch)
 
     def _run_head(self, x: torch.Tensor) -> torch.Tensor:
         dev = self._ensure_engine()
         assert x.dim() == 3 and x.shape[2] == self._arch.dim, "expected the backbone output (B, L, dim)"
         x = self._as_input(x, dev)
         B, L, _ = x.shape
-        plan, ws = self._engine.plan(_capi.WT_PLAN_HEAD, B, L, self._plan_flags, dev)
-        wav = torch.empty((B, L * self._arch.hop_length), dtype=torch.float32, device=dev)
-        check(lib.wt_head(plan, _ptr(x), _ptr(wav), _ptr(ws), _stream_ptr(dev)), "wt_head")
-        return wav
+
+        def launch(plan, ws):
+            wav = torch.empty((B, L * self._arch.hop_length), dtype=torch.float32, device=dev)
+            check(lib.wt_head(plan, _ptr(x), _ptr(wav), _ptr(ws), _stream_ptr(dev)), "wt_head")
+            return wav
+
+        return self._guarded(dev, lambda: self._engine.plan(_capi.WT_PLAN_HEAD, B, L, self._plan_flags, dev), launch)
 
     def _run_seanet_decoder(self, z: torch.Tensor) -> torch.Tensor:
         dev = self._ensure_engine()
         z = self._as_input(z, dev)
         B, _, L = z.shape
-        plan, ws = self._engine.plan(_capi.WT_PLAN_SEANET_DECODER, B, L, self._plan_flags, dev)
-        out = torch.empty((B, 1, L * self._arch.hop), dtype=torch.float32, device=dev)
-        check(lib.wt_seanet_decode(plan, _ptr(z), _ptr(out), _ptr(ws), _stream_ptr(dev)), "wt_seanet_decode")
-        return out
 
-    def debug_stage(self, kind: int, B: int, length: int, name: str) -> torch.Tensor:
-        """Flat fp32 view of a named stage buffer of the cached plan (after a KEEP_STAGES run)."""
+        def launch(plan, ws):
+            out = torch.empty((B, 1, L * self._arch.hop), dtype=torch.float32, device=dev)
+            check(lib.wt_seanet_decode(plan, _ptr(z), _ptr(out), _ptr(ws), _stream_ptr(dev)), "wt_seanet_decode")
+            return out
+
+        return self._guarded(dev, lambda: self._engine.plan(_capi.WT_PLAN_SEANET_DECODER, B, L, self._plan_flags, dev), launch)
+
+    def _run_unit_lstm(self, x: torch.Tensor) -> torch.Tensor:
+        """Unit tests: the encoder's SLSTM alone, x (B, L, 512) time-major -> lstm(x) + x, on the plan's kernels."""
+        dev = self._ensure_engine()
+        x = self._as_input(x, dev)
+        B, L, _ = x.shape
+        plan, ws = self._engine.plan(_capi.WT_PLAN_UNIT_LSTM, B, L, self._plan_flags, dev)
+        y = torch.empty_like(x)
+        check(lib.wt_unit_run(plan, _ptr(x), _ptr(y), _ptr(ws), _stream_ptr(dev)), "wt_unit_run")
+        return y
+
+    def debug_stage(self, kind: int, B: int, length: int, name: str, rows: Optional[int] = None):
+        """A named stage buffer of the cached plan (after a KEEP_STAGES run), decoded to fp32: returns (flat tensor,
+        format bits); format & BUF_ELU says the buffer holds elu() of the reference's tensor.  S32 buffers are decoded
+        (rows x cols with cols = numel / rows: pass `rows` for them)."""
         plan, ws = self._engine.plans[(kind, B, length, self._plan_flags)]
-        off, n = ctypes.c_size_t(), ctypes.c_size_t()
-        check(lib.wt_plan_find_buffer(plan, name.encode(), ctypes.byref(off), ctypes.byref(n)), "wt_plan_find_buffer")
-        return ws[off.value: off.value + 4 * n.value].view(torch.float32)
+        off, n, fmt = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_int32()
+        check(lib.wt_plan_buffer_info(plan, name.encode(), ctypes.byref(off), ctypes.byref(n), ctypes.byref(fmt)),
+              "wt_plan_buffer_info")
+        raw = ws[off.value: off.value + 4 * n.value]
+        if fmt.value & _capi.BUF_S32:
+            h = raw.view(torch.float16).view(-1, 2, 32).float()        # groups of [32 hi | 32 lo]
+            return (h[:, 0, :] + h[:, 1, :] / 2048.0).reshape(-1), fmt.value
+        return raw.view(torch.float32), fmt.value
 
     # -- reference API (pretrained.py:159-239) --------------------------------------------------------
     @torch.inference_mode()
@@ -527,4 +630,10 @@ class WavTokenizer(nn.Module):
         feats = torch.empty((B, 512, L), dtype=torch.float32, device=dev)
         check(lib.wt_codes_to_features(self._engine.model, _ptr(codes), K, B, L, _ptr(feats), _stream_ptr(dev)),
               "wt_codes_to_features")
+        if self._check_codes:
+            # F.embedding raises on an index outside the codebook (pretrained.py:236); the kernel flags it instead (and
+            # writes NaN), which is read here after the (few microseconds of) work has completed
+            torch.cuda.current_stream(dev).synchronize()
+            if lib.wt_model_take_bad_codes(self._engine.model):
+                raise IndexError("index out of range in self")
         return feats
