@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — audio-seconds/sec of WavTokenizer encode_infer + decode on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--arch hop600|hop320] [--clips 64]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--repeats R] [--arch hop600|hop320] [--clips 64]
 
 One "step" = one encode_infer + decode round trip of `--clips` independent 3 s / 24 kHz clips
 per GPU (BASELINE.json configs[1]: WavTokenizer-small-600, batch 64 x 3 s), inputs already
@@ -11,19 +11,28 @@ torch.distributed.run; clips shard across ranks with no collective on the data p
 scaling) and the per-step codes all-gather + waveform gather to rank 0 over RCCL is inside the
 timed region.  Rank 0 prints ONE JSON line.
 
+Timing: W warm-up steps, then R blocks of exactly K steps, each block bracketed by a barrier +
+torch.cuda.synchronize() on both sides and reduced with MAX over ranks.  `ms_per_step` / `value` are
+the MEDIAN block (a single 0.13 s block is a thin basis: the min / max over the blocks are on the line too).
+
 Extra objects on the line:
-  roofline     — dominant kernel (ConvNeXt pwconv1 GEMM + GELU, 12 launches per step): achieved =
-                 algorithmic 2*M*N*K per launch / mean launch duration, from HIP events recorded on the
-                 launch stream during the timed steps (wt_plan_set_timing).  The kernel evaluates every
-                 fp32-equivalent product with THREE v_mfma_f32_32x32x16_f16 (split-f16, gemm16s.hip), so
-                 its MFMA roofline in algorithmic (fp32-equivalent) FLOP/s is the dense f16 peak / 3.
-  cpu_baseline — the oracle (oracle/cpu_ref.py, same ATen op sequence as the reference) timed on
-                 this host's cores, rank 0 at N=1 only, on a bounded sample of the same workload.
+  roofline      — dominant kernel (ConvNeXt pwconv1 GEMM + GELU, 12 launches per step): achieved =
+                  algorithmic 2*M*N*K per launch / mean launch duration, from HIP events recorded on the
+                  launch stream during the timed steps (wt_plan_set_timing).  The kernel evaluates every
+                  fp32-equivalent product with THREE v_mfma_f32_32x32x16_f16 (split-f16, gemm16s.hip), so
+                  its MFMA roofline in algorithmic (fp32-equivalent) FLOP/s is the dense f16 peak / 3.
+  cpu_baseline  — the oracle (oracle/cpu_ref.py, same ATen op sequence as the reference) timed on
+                  this host's cores, rank 0 at N=1 only, on a bounded sample of the same workload
+                  (BASELINE.md section 3 protocol: 3 warm-ups, median of >= 10 round trips; B = 1, 16, 64; 8 threads too).
+  other_configs — N=1 only: BASELINE configs[2] (hop-320, 64 x 3 s), the per-GPU share of configs[4]
+                  (hop-600, 32 x 30 s: p50 encode_infer latency, codes/s) and the reference's own usage
+                  (infer.py:44-70: one clip at a time, a different length per file, bandwidth_id on the GPU).
 """
 import argparse
 import ctypes
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -32,11 +41,8 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA_TFLOPS = 2516.6     # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (256 CUs x 4 SIMDs x 1024 flop/clk x 2.4 GHz)
 PEAK_F16X3_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0   # fp32-equivalent products on the f16 pipe: 3 MFMAs each
-HBM_PEAK_GBS = 8000.0
-CLIP_SECONDS = 3
 SAMPLE_RATE = 24000
 # algorithmic GFLOP per 3 s clip (2*MAC: convs, linears, LSTM, VQ, attention)
 GFLOP_PER_CLIP = {"hop600": 20.852, "hop320": 38.910}
@@ -44,55 +50,74 @@ WORKLOAD = {"hop600": "WavTokenizer-small-600-24k-4096 (40 tok/s), encode_infer+
             "hop320": "WavTokenizer-small-320-24k-4096 (75 tok/s), encode_infer+decode round trip, 24 kHz clips"}
 
 
-def cpu_baseline(arch_name, sd, clips_np):
-    """Oracle on the host cores.  torch's default thread count (= all cores) oversubscribes this
-    small model, so a few thread counts are tried on a B=16 batch and the fastest is kept; B=1
-    (BASELINE configs[0]) is timed at that count too.  ~30 s of CPU work in total."""
+def gflop_per_clip(arch_name, arch, clip_seconds):
+    """SURVEY 8(d) FLOPs are for 3 s clips; everything is linear in the length except attention (4*L^2*dim per clip)."""
+    L = arch.frames(clip_seconds * SAMPLE_RATE)
+    L3 = arch.frames(3 * SAMPLE_RATE)
+    return GFLOP_PER_CLIP[arch_name] * clip_seconds / 3.0 + 4.0 * arch.dim * (L * L - L3 * L3 * clip_seconds / 3.0) / 1e9
+
+
+def cpu_baseline(arch_name, sd, clips_np, clip_seconds):
+    """Oracle on the host cores, BASELINE.md section 3: fp32, inputs in RAM, 3 warm-ups then the median of >= 10 round
+    trips per row.  torch's default thread count (= all cores) oversubscribes this small model, so a few thread counts
+    are tried on a B = 16 batch first; rows: B = 1 (BASELINE configs[0]), 16 and 64 at the best count, B = 1 and 16 at
+    8 threads (comparable with the 8-CPU development container).  Bounded to ~2.5 minutes of CPU work."""
     from oracle.cpu_ref import OracleWavTokenizer
     from wavtokenizer_amd import NAMED_ARCHS
     orc = OracleWavTokenizer(NAMED_ARCHS[arch_name], sd)
     bw = torch.tensor([0])
     ncpu = os.cpu_count() or 1
-    deadline = time.time() + 60.0
+    deadline = time.time() + 150.0
 
-    def rate(B, reps):
+    def rate(B, reps, warm=3):
         x = torch.from_numpy(clips_np[:B])
+        ts = []
         with torch.inference_mode():
-            f, _ = orc.encode_infer(x, bw)      # warm-up
-            orc.decode(f, bw)
-            ts = []
+            for _ in range(warm):
+                f, _ = orc.encode_infer(x, bw)
+                orc.decode(f, bw)
+                if time.time() > deadline:
+                    break
             for _ in range(reps):
                 t0 = time.perf_counter()
                 f, _ = orc.encode_infer(x, bw)
                 orc.decode(f, bw)
                 ts.append(time.perf_counter() - t0)
-                if time.time() > deadline:
+                if time.time() > deadline and len(ts) >= 3:
                     break
-        ts.sort()
-        return B * CLIP_SECONDS / ts[len(ts) // 2]
+        return B * clip_seconds / statistics.median(ts), len(ts)
 
     tried = {}
     for nt in sorted({min(ncpu, n) for n in (8, 16, 32, 64)}):     # all-cores (>64) only thrashes
         torch.set_num_threads(nt)
-        tried[nt] = rate(16, 2)
+        tried[nt] = rate(16, 2, warm=1)[0]
     best_nt = max(tried, key=tried.get)
+    rows = {}
     torch.set_num_threads(best_nt)
-    r16 = rate(16, 3)
-    r1 = rate(1, 8)
-    value = max(r16, r1)
+    for B in sorted({1, min(16, len(clips_np)), min(64, len(clips_np))}):
+        r, n = rate(B, 10)
+        rows[f"B={B},threads={best_nt}"] = {"audio_s_per_s": round(r, 2), "round_trips": n}
+    if best_nt != min(8, ncpu):
+        torch.set_num_threads(min(8, ncpu))
+        for B in sorted({1, min(16, len(clips_np))}):
+            r, n = rate(B, 10)
+            rows[f"B={B},threads={min(8, ncpu)}"] = {"audio_s_per_s": round(r, 2), "round_trips": n}
+    torch.set_num_threads(best_nt)
+    value = max(v["audio_s_per_s"] for k, v in rows.items() if k.endswith(f"threads={best_nt}"))
     return {"value": round(value, 2), "unit": "audio-s/s", "cores": best_nt, "kind": "port",
-            "sample": "oracle/cpu_ref.py (the reference's ATen op sequence, fp32); thread sweep on B=16 x3s: %s; at %d threads "
-                      "median round trip B=16 x3s (3 reps): %.1f audio-s/s, B=1 x3s (8 reps): %.1f audio-s/s; value = the faster; "
-                      "host has %d logical CPUs"
-                      % (", ".join(f"{k}t={v:.1f}" for k, v in sorted(tried.items())), best_nt, r16, r1, ncpu)}
+            "rows": rows,
+            "sample": "oracle/cpu_ref.py (the reference's ATen op sequence, fp32), encode_infer+decode round trips of %d s clips: "
+                      "3 warm-ups then the median of up to 10 per row; thread sweep on B=16 (2 reps): %s; value = the fastest row at "
+                      "%d threads; host has %d logical CPUs"
+                      % (clip_seconds, ", ".join(f"{k}t={v:.1f}" for k, v in sorted(tried.items())), best_nt, ncpu)}
 
 
-def pmc_traffic(arch_name, B):
+def pmc_traffic(arch_name, B, clip_seconds):
     """Bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate
     FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected: tools/summarize_profile.py); None if there is
     no summary for this workload.  PMC counters cannot be read from inside the timed process."""
     import glob
-    if arch_name != "hop600" or B != 64 or CLIP_SECONDS != 3:
+    if arch_name != "hop600" or B != 64 or clip_seconds != 3:
         return None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
@@ -105,16 +130,67 @@ def pmc_traffic(arch_name, B):
     return None
 
 
+def make_model(arch_name, dev):
+    from wavtokenizer_amd import WavTokenizer, NAMED_ARCHS, synth
+    arch = NAMED_ARCHS[arch_name]
+    sd = synth.make_state_dict(arch, seed=0)
+    t0 = time.perf_counter()
+    model = WavTokenizer.from_arch(arch)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    model = model.eval().to(dev)
+    model._ensure_engine()              # fold + pack + upload now, not inside the first step
+    torch.cuda.synchronize()
+    return model, arch, sd, time.perf_counter() - t0
+
+
+class Runner:
+    """encode_infer + decode steps of one (model, batch) with the end-of-step exchange of the sharded mode."""
+
+    def __init__(self, model, wav, bw, dist, world, rank, gather, backend):
+        self.model, self.wav, self.bw = model, wav, bw
+        self.dist, self.world, self.rank, self.gather, self.backend = dist, world, rank, gather and world > 1, backend
+        self.prev = None            # (codes, waveform) of the previous step, not yet exchanged
+
+    def _issue(self):
+        from wavtokenizer_amd.sharding import gather_async
+        codes, out = self.prev
+        self.prev = None
+        if self.backend == "gloo":                               # rehearsal only: through host memory
+            codes, out = codes.cpu(), out.cpu()
+        return gather_async(codes, out, self.dist, self.world, self.rank, dst=0)
+
+    def step(self):
+        # The exchange of step i (codes to every rank, 8*L bytes per clip; waveforms to rank 0, 18.4 MB per rank) is issued
+        # AFTER step i+1's encode_infer has been enqueued and collected before step i+1 returns: RCCL's kernels start
+        # once that encode has finished on the GPU and run beside the decode, never beside lstm_persist_kernel, which needs
+        # every CU for its resident workgroups (wavtokenizer_amd/csrc/lstm_persist.hip); the next encode is ordered
+        # behind the collective by its stream wait.
+        feats, codes = self.model.encode_infer(self.wav, bandwidth_id=self.bw)
+        pend = self._issue() if (self.gather and self.prev is not None) else None
+        out = self.model.decode(feats, bandwidth_id=self.bw)
+        res = pend.result() if pend is not None else None
+        if self.gather:
+            self.prev = (codes, out)
+        return codes, out, res
+
+    def drain(self):
+        """The exchange of the last step: issued and collected here, inside the timed region."""
+        if self.gather and self.prev is not None:
+            return self._issue().result()
+        return None
+
+
 def main():
-    global CLIP_SECONDS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps; the line carries the median block")
     ap.add_argument("--arch", default="hop600", choices=["hop600", "hop320"])
     ap.add_argument("--clips", type=int, default=64, help="clips per GPU per step")
     ap.add_argument("--clip-seconds", type=int, default=3, help="clip length (BASELINE configs[4] uses 30 s clips)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured path); gloo only rehearses the N>1 flow on a box with "
@@ -143,43 +219,7 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    from wavtokenizer_amd import WavTokenizer, NAMED_ARCHS, synth, _capi
-    arch = NAMED_ARCHS[args.arch]
-    sd = synth.make_state_dict(arch, seed=0)
-    model = WavTokenizer.from_arch(arch)
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
-    model = model.eval().to(dev)
-    CLIP_SECONDS = args.clip_seconds
-    B, T = args.clips, CLIP_SECONDS * SAMPLE_RATE
-    clips_np = synth.make_clips(B, T, seed=1000 * 2 + rank)       # seed = 1000*config + index
-    wav = torch.from_numpy(clips_np).to(dev)
-    bw = torch.tensor([0])
-    L = arch.frames(T)
-
-    from wavtokenizer_amd.sharding import gather_async
-
-    # The end-of-step exchange (codes to every rank, 8*L bytes per clip; waveforms to rank 0, 18.4 MB per rank) is
-    # issued asynchronously: RCCL moves step i's outputs over xGMI while step i+1's kernels run, and step i's result is
-    # collected right before step i+1's exchange is issued (the last one before the closing barrier), so every
-    # exchange is finished inside the timed region.
-    pending = []
-
-    def step():
-        feats, codes = model.encode_infer(wav, bandwidth_id=bw)
-        out = model.decode(feats, bandwidth_id=bw)
-        if world > 1 and not args.no_gather:
-            if args.backend == "gloo":                               # rehearsal only: through host memory
-                codes, out = codes.cpu(), out.cpu()
-            while pending:
-                pending.pop().result()
-            pending.append(gather_async(codes, out, dist, world, rank, dst=0))
-        return codes, out
-
-    def drain():
-        res = None
-        while pending:
-            res = pending.pop().result()
-        return res
+    from wavtokenizer_amd import synth, _capi
 
     def barrier():
         torch.cuda.synchronize()
@@ -187,80 +227,210 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    drain()
-    barrier()
-    # time the dominant kernel with HIP events on its launch stream during the timed steps
-    dplan = model._engine.plans[(_capi.WT_PLAN_DECODE, B, L, model._graph_flags(B))][0]
-    _capi.check(_capi.lib.wt_plan_set_timing(dplan, b"cnx.pwconv1"), "wt_plan_set_timing")
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    tot_ms, n_l = ctypes.c_double(), ctypes.c_int64()
-    _capi.check(_capi.lib.wt_plan_read_timing(dplan, ctypes.byref(tot_ms), ctypes.byref(n_l), 1), "wt_plan_read_timing")
-    _capi.lib.wt_plan_set_timing(dplan, b"")
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    # BASELINE configs[4] also asks for the p50 latency of one encode_infer call: a few synchronised calls after the
-    # timed region (not part of `value`)
+    def run_blocks(runner, steps, warmup, repeats, time_plan=None):
+        """W warm-up steps, then `repeats` blocks of exactly `steps` steps; returns the per-block seconds (MAX over
+        ranks) and, with time_plan = (plan, step-name filter), the HIP-event time of those launches."""
+        for _ in range(warmup):
+            runner.step()
+        runner.drain()
+        barrier()
+        if time_plan:
+            _capi.check(_capi.lib.wt_plan_set_timing(time_plan[0], time_plan[1]), "wt_plan_set_timing")
+        blocks = []
+        for _ in range(repeats):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                runner.step()
+            runner.drain()
+            barrier()
+            blocks.append(max_over_ranks(time.perf_counter() - t0))
+        kern = None
+        if time_plan:
+            tot_ms, n_l = ctypes.c_double(), ctypes.c_int64()
+            _capi.check(_capi.lib.wt_plan_read_timing(time_plan[0], ctypes.byref(tot_ms), ctypes.byref(n_l), 1), "wt_plan_read_timing")
+            _capi.lib.wt_plan_set_timing(time_plan[0], b"")
+            kern = (tot_ms.value, n_l.value)
+        return blocks, kern
+
+    # ------------------------------------------------------------------------------ the headline workload
+    model, arch, sd, load_s = make_model(args.arch, dev)
+    clip_s = args.clip_seconds
+    B, T = args.clips, clip_s * SAMPLE_RATE
+    clips_np = synth.make_clips(B, T, seed=1000 * 2 + rank)       # SURVEY 8(d): seed = 1000*config + index
+    wav = torch.from_numpy(clips_np).to(dev)
+    bw = torch.tensor([0])
+    L = arch.frames(T)
+    runner = Runner(model, wav, bw, dist, world, rank, not args.no_gather, args.backend)
+    runner.step()                                                  # creates the plans
+    runner.drain()
+    dplan = model._engine.plans[(_capi.WT_PLAN_DECODE, B, L, model._graph_flags(B))][0]
+    blocks, kern = run_blocks(runner, args.steps, max(0, args.warmup - 1), args.repeats, (dplan, b"cnx.pwconv1"))
+    model.check_status()
+
     p50_encode_ms = None
-    if CLIP_SECONDS >= 30:
+    if clip_s >= 30:       # BASELINE configs[4] also asks for the p50 latency of one encode_infer call
         lat = []
-        for _ in range(5):
+        for _ in range(7):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             model.encode_infer(wav, bandwidth_id=bw)
             e1.record()
             e1.synchronize()
             lat.append(e0.elapsed_time(e1))
-        p50_encode_ms = sorted(lat)[len(lat) // 2]
+        p50_encode_ms = statistics.median(lat)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    line = None
     if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        value = world * B * CLIP_SECONDS * args.steps / elapsed
+        per_step = sorted(1e3 * b / args.steps for b in blocks)
+        ms_per_step = statistics.median(per_step)
+        value = world * B * clip_s / (ms_per_step * 1e-3)
         Mrows = B * L
         flops = 2.0 * Mrows * arch.intermediate_dim * arch.dim
-        kern_ms = tot_ms.value / max(1, n_l.value)
+        kern_ms = kern[0] / max(1, kern[1])
         achieved = flops / (kern_ms * 1e-3) / 1e12
-        # SURVEY 8(d) FLOPs are for 3 s clips; attention grows with L^2 (4*L^2*768 per clip)
-        gflop_clip = GFLOP_PER_CLIP[args.arch] * CLIP_SECONDS / 3.0 + 4.0 * arch.dim * (L * L - (L * 3 // CLIP_SECONDS) ** 2 * CLIP_SECONDS / 3.0) / 1e9
-        e2e_tflops = gflop_clip * B * 1e9 / (ms_per_step * 1e-3) / 1e12
+        e2e_tflops = gflop_per_clip(args.arch, arch, clip_s) * B * 1e9 / (ms_per_step * 1e-3) / 1e12
         line = {
-            "metric": "audio-seconds/sec encode+decode, 24 kHz %d s clips" % CLIP_SECONDS,
+            "metric": "audio-seconds/sec encode+decode, 24 kHz %d s clips" % clip_s,
             "value": round(value, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "dtype_note": "fp32 storage and accumulation; dense layers form each fp32 product from split f16 operands (3 MFMAs, error below the fp32 chain's own rounding)",
             "data": "synthetic",
+            "timing": {"blocks": len(per_step), "steps_per_block": args.steps, "statistic": "median block",
+                       "ms_per_step_min": round(per_step[0], 3), "ms_per_step_max": round(per_step[-1], 3),
+                       "ms_per_step_blocks": [round(x, 3) for x in per_step],
+                       "value_min": round(world * B * clip_s / (per_step[-1] * 1e-3), 1),
+                       "value_max": round(world * B * clip_s / (per_step[0] * 1e-3), 1)},
             "config": {"workload": WORKLOAD[args.arch], "arch": args.arch, "clips_per_gpu": B,
-                       "global_clips": world * B, "clip_seconds": CLIP_SECONDS, "frames_per_clip": L,
-                       "codes_per_sec": round(world * B * L * args.steps / elapsed, 1),
+                       "global_clips": world * B, "clip_seconds": clip_s, "frames_per_clip": L,
+                       "codes_per_sec": round(world * B * L / (ms_per_step * 1e-3), 1),
                        **({"p50_encode_infer_ms_rank0": round(p50_encode_ms, 3)} if p50_encode_ms is not None else {}),
-                       "weights": "random-init (synth seed 0)", "parallelism": f"clips sharded dp{world}",
-                       "gather": ("codes all_gather + waveform gather to rank 0 (%s), asynchronous: overlaps the next step, all finished inside the timed region" % ("RCCL" if args.backend == "nccl" else "gloo rehearsal")) if world > 1 and not args.no_gather else "none"},
+                       "weights": "random-init (synth seed 0)", "model_load_s": round(load_s, 2), "parallelism": f"clips sharded dp{world}",
+                       "gather": ("codes all_gather + waveform gather to rank 0 (%s), asynchronous: step i's exchange runs beside step i+1's decode "
+                                  "(never beside the persistent LSTM), all finished inside the timed region" % ("RCCL" if args.backend == "nccl" else "gloo rehearsal"))
+                       if world > 1 and not args.no_gather else "none"},
             "roofline": {"bound": "mfma",
                          "kernel": "wt::gemm16s_kernel<128,192,4,2,3,EPI_BIAS_GELU=2,OUT_S32=1> (ConvNeXt pwconv1 GEMM %dx%dx%d + GELU, "
                                    "split-f16: 3 x v_mfma_f32_32x32x16_f16 per fp32-equivalent product)" % (Mrows, arch.intermediate_dim, arch.dim),
                          "achieved": round(achieved, 2), "peak": round(PEAK_F16X3_TFLOPS, 1), "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F16X3_TFLOPS, 4), "traffic": pmc_traffic(args.arch, B),
+                         "frac": round(achieved / PEAK_F16X3_TFLOPS, 4), "traffic": pmc_traffic(args.arch, B, clip_s),
                          "peak_note": "algorithmic fp32-equivalent FLOP/s; peak = %.1f TF dense f16 MFMA / 3 MFMAs per product; the kernel "
                                       "issues %.0f TF/s of f16 MFMA work" % (PEAK_F16_MFMA_TFLOPS, 3 * achieved),
                          "algorithmic_bytes_per_launch": 4 * (Mrows * arch.dim + arch.intermediate_dim * arch.dim + Mrows * arch.intermediate_dim),
-                         "flops_per_launch": flops, "avg_launch_ms": round(kern_ms, 4), "launches_timed": n_l.value,
+                         "flops_per_launch": flops, "avg_launch_ms": round(kern_ms, 4), "launches_timed": kern[1],
                          "end_to_end_tflops": round(e2e_tflops, 2),
-                         "end_to_end_frac_of_fp32_mfma_peak": round(e2e_tflops / PEAK_FP32_MFMA_TFLOPS, 4)},
+                         "end_to_end_frac": round(e2e_tflops / PEAK_F16X3_TFLOPS, 4)},
         }
+
+    # ------------------------------------------------------------------------------ other configs (N = 1)
+    if world == 1 and rank == 0 and not args.no_other_configs and args.arch == "hop600" and clip_s == 3:
+        other = {}
+        # the reference's own usage (infer.py:44-70): one clip per call, a different length per file, bandwidth_id built
+        # on the GPU once; >= 20 distinct lengths between 1 and 10 s
+        import numpy as np
+        rng = np.random.default_rng(2024)
+        lengths = sorted({int(x) for x in rng.integers(SAMPLE_RATE, 10 * SAMPLE_RATE, size=24)})
+        bw_dev = torch.tensor([0]).to(dev)
+        clips1 = [torch.from_numpy(synth.make_clips(1, t, seed=77 + i)).to(dev) for i, t in enumerate(lengths)]
+        torch.cuda.synchronize()
+        first, plan_ms = [], []
+        for x in clips1:
+            t0 = time.perf_counter()
+            p = ctypes.c_void_p()
+            _capi.check(_capi.lib.wt_plan_create(model._engine.model, _capi.WT_PLAN_ENCODE, 1, x.shape[1], 0, ctypes.byref(p)), "plan")
+            plan_ms.append(1e3 * (time.perf_counter() - t0))
+            _capi.lib.wt_plan_destroy(p)
+            t0 = time.perf_counter()
+            f, c = model.encode_infer(x, bandwidth_id=bw_dev)
+            y = model.decode(f, bandwidth_id=bw_dev)
+            torch.cuda.synchronize()
+            first.append(1e3 * (time.perf_counter() - t0))
+        steady = []
+        for rep in range(3):
+            for x in clips1:
+                t0 = time.perf_counter()
+                f, c = model.encode_infer(x, bandwidth_id=bw_dev)
+                y = model.decode(f, bandwidth_id=bw_dev)
+                torch.cuda.synchronize()
+                if rep:
+                    steady.append(1e3 * (time.perf_counter() - t0))
+        # ... and back to back without a host synchronisation per file (what a pipelined caller gets)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for rep in range(2):
+            for x in clips1:
+                f, c = model.encode_infer(x, bandwidth_id=bw_dev)
+                y = model.decode(f, bandwidth_id=bw_dev)
+        torch.cuda.synchronize()
+        pipelined_ms = 1e3 * (time.perf_counter() - t0) / (2 * len(clips1))
+        audio_s = sum(lengths) / SAMPLE_RATE
+        other["infer_py_loop_B1_variable_length"] = {
+            "reference_usage": "infer.py:44-70: one clip per encode_infer/decode call, a new length per file, bandwidth_id tensor on the GPU",
+            "files": len(lengths), "seconds_per_file_min_max": [round(lengths[0] / SAMPLE_RATE, 2), round(lengths[-1] / SAMPLE_RATE, 2)],
+            "plan_create_ms_median": round(statistics.median(plan_ms), 3),
+            "first_call_ms_median": round(statistics.median(first), 3), "first_call_ms_max": round(max(first), 3),
+            "steady_state_ms_median": round(statistics.median(steady), 3), "steady_state_ms_max": round(max(steady), 3),
+            "pipelined_ms_per_file": round(pipelined_ms, 3),
+            "audio_s_per_s_synchronised": round(audio_s / (sum(steady) / 2 / 1e3), 1),
+            "audio_s_per_s_pipelined": round(audio_s / (pipelined_ms * len(lengths) / 1e3), 1),
+            "plans_cached": len(model._engine.plans)}
+        model.check_status()
+
+        # BASELINE configs[4], per-GPU share: hop-600, 32 clips x 30 s
+        wav30 = torch.from_numpy(synth.make_clips(32, 30 * SAMPLE_RATE, seed=1000 * 4)).to(dev)
+        r30 = Runner(model, wav30, bw, None, 1, 0, False, args.backend)
+        r30.step()
+        blk, _ = run_blocks(r30, 5, 1, 3)
+        ms30 = statistics.median(1e3 * b / 5 for b in blk)
+        lat = []
+        for _ in range(7):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            model.encode_infer(wav30, bandwidth_id=bw)
+            e1.record()
+            e1.synchronize()
+            lat.append(e0.elapsed_time(e1))
+        L30 = arch.frames(30 * SAMPLE_RATE)
+        other["hop600_32x30s"] = {
+            "baseline_config": "configs[4] per-GPU share: WavTokenizer-large-600 architecture, 32 clips x 30 s",
+            "ms_per_step": round(ms30, 3), "audio_s_per_s": round(32 * 30 / (ms30 * 1e-3), 1),
+            "codes_per_sec": round(32 * L30 / (ms30 * 1e-3), 1), "p50_encode_infer_ms": round(statistics.median(lat), 3),
+            "end_to_end_tflops": round(gflop_per_clip("hop600", arch, 30) * 32 * 1e9 / (ms30 * 1e-3) / 1e12, 2),
+            "steps": 5, "blocks": 3}
+        model.check_status()
+        del wav30, r30
+        model._engine.close()
+        model._dirty = True
+        torch.cuda.empty_cache()
+
+        # BASELINE configs[2]: hop-320, 64 x 3 s
+        m320, a320, _sd320, load320 = make_model("hop320", dev)
+        wav320 = torch.from_numpy(synth.make_clips(64, 3 * SAMPLE_RATE, seed=1000 * 3)).to(dev)
+        r320 = Runner(m320, wav320, bw, None, 1, 0, False, args.backend)
+        r320.step()
+        blk, _ = run_blocks(r320, 10, 2, 3)
+        ms320 = statistics.median(1e3 * b / 10 for b in blk)
+        other["hop320_64x3s"] = {
+            "baseline_config": "configs[2]: WavTokenizer-small-320 (75 tok/s), 64 clips x 3 s",
+            "ms_per_step": round(ms320, 3), "audio_s_per_s": round(64 * 3 / (ms320 * 1e-3), 1),
+            "codes_per_sec": round(64 * a320.frames(3 * SAMPLE_RATE) / (ms320 * 1e-3), 1),
+            "end_to_end_tflops": round(GFLOP_PER_CLIP["hop320"] * 64 * 1e9 / (ms320 * 1e-3) / 1e12, 2),
+            "model_load_s": round(load320, 2), "steps": 10, "blocks": 3}
+        m320.check_status()
+        del m320, wav320, r320
+        line["other_configs"] = other
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.arch, sd, clips_np)
-            line["speedup_vs_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
+            line["cpu_baseline"] = cpu_baseline(args.arch, sd, clips_np, clip_s)
+            line["speedup_vs_cpu"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -877,3 +877,26 @@ def test_codes_out_of_range_raise_like_embedding(gpu_model):
         with pytest.raises(IndexError):
             m.codes_to_features(c)
     assert torch.isfinite(m.codes_to_features(codes)).all()      # the flag does not stick
+
+
+def test_graph_replay_single_clip_alternating_plans(gpu_model):
+    """The reference's own usage (infer.py:44-70): one clip per call.  Encode and decode graphs replay alternately; every
+    replay must equal the direct launches bit for bit.  (Round 2 regression: hipMemsetAsync nodes replayed from a hipGraph
+    left garbage at the start of their destination — the V^T pad fill and the LSTM exchange buffers; fills are kernels now.)"""
+    from wavtokenizer_amd import synth
+    name, m, _sd = gpu_model
+    for T in (24000, 36963):
+        x = torch.from_numpy(synth.make_clips(1, T, seed=77)).cuda()
+        m.set_graph_max_clips(0)
+        try:
+            f0, c0 = m.encode_infer(x, bandwidth_id=BW)
+            y0 = m.decode(f0, bandwidth_id=BW)
+        finally:
+            m.set_graph_max_clips(16)
+        for rep in range(5):
+            f, c = m.encode_infer(x, bandwidth_id=BW)
+            y = m.decode(f, bandwidth_id=BW)
+            assert torch.equal(c, c0), (T, rep)
+            assert torch.equal(f, f0), (T, rep)
+            assert torch.equal(y, y0), (T, rep)
+    m.check_status()

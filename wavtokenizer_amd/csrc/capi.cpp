@@ -249,6 +249,13 @@ static int run_plan_locked(const wt_plan* p, const RunCtx& c) {
             WT_HIP_CHECK(hipEventRecord(ev.first, c.stream));
         }
         if (int rc = p->steps[i](c)) return rc;
+        static const bool dbg_status = getenv("WT_DEBUG_STATUS") != nullptr;
+        if (dbg_status) {        // debugging aid: which step left a non-zero status word (synchronises after every step)
+            unsigned st = 0;
+            WT_HIP_CHECK(hipStreamSynchronize(c.stream));
+            WT_HIP_CHECK(hipMemcpy(&st, c.ws + p->bufs[p->ctl].off, sizeof(st), hipMemcpyDeviceToHost));
+            if (st) fprintf(stderr, "[wt status] plan kind %d B %d len %ld: step %zu (%s) -> status 0x%08x\n", p->kind, p->B, (long)p->len, i, p->step_names[i].c_str(), st);
+        }
         if (timed) {
             WT_HIP_CHECK(hipEventRecord(ev.second, c.stream));
             p->ev_pending.push_back(ev);

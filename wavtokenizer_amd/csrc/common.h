@@ -50,10 +50,16 @@ extern thread_local LaunchCtx g_launch;
 
 #if defined(__HIPCC__)
 // largest |v| of a value that is being converted to the split-f16 form; NaNs are ignored (they propagate by themselves)
+#ifdef WT_NO_RANGE_TRACK        // A/B timing builds only (tools/ab_lib.sh): what the tracking costs
+__device__ __forceinline__ float amax1(float m, float) { return m; }
+__device__ __forceinline__ float amax4(float m, float, float, float, float) { return m; }
+#else
 __device__ __forceinline__ float amax1(float m, float v) { return fmaxf(m, fabsf(v)); }
-__device__ __forceinline__ float amax4(float m, float a, float b, float c, float d) {
-    return fmaxf(fmaxf(m, fmaxf(fabsf(a), fabsf(b))), fmaxf(fabsf(c), fabsf(d)));
+__device__ __forceinline__ float amax4(float m, float a, float b, float c, float d) {      // two v_max3_f32 with |.| source modifiers
+    m = fmaxf(fmaxf(m, fabsf(a)), fabsf(b));
+    return fmaxf(fmaxf(m, fabsf(c)), fabsf(d));
 }
+#endif
 __device__ __forceinline__ void range_report(unsigned* status, float amax) {
     if (status && amax >= 65504.f) __hip_atomic_fetch_or(status, (unsigned)WT_STATUS_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -173,6 +179,8 @@ int launch_vq_finalize(const float* pval, const int* pidx, int nparts, const flo
                        float* feat_ncl, int B, int L, int D, int bins, hipStream_t s);
 int launch_codes_to_features(const int64_t* codes, const float* embed, int K, int bins, int B, long L, int D,
                              float* feat_ncl, hipStream_t s, unsigned* bad = nullptr);
+// buffer fill as a kernel (hipMemsetAsync nodes misbehave under hipGraph replay: ops.hip); 16-byte aligned pointer and size
+int launch_fill_u32(void* p, unsigned value, size_t n_bytes, hipStream_t s);
 // last step of every plan: on a non-zero status word poison the outputs (codes = -1, floats = NaN) and publish the bits
 int launch_plan_guard(const unsigned* status, unsigned* host_status, int64_t* codes, long n_codes, float* f0, long n0,
                       float* f1, long n1, float* f2, long n2, hipStream_t s);

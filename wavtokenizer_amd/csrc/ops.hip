@@ -837,6 +837,24 @@ __global__ __launch_bounds__(256) void plan_guard_kernel(const unsigned* __restr
     if (f2) for (long i = i0; i < n2; i += step) f2[i] = qnan;
 }
 
+// Fills of plan buffers are kernels, never hipMemsetAsync: replayed from a hipGraph, the memset nodes of ROCm 7.2 were
+// seen to leave eight bytes of garbage (a host address) at the start of their destination AFTER later nodes had
+// written there (found through the call status word; it also explained codes that differed between direct and
+// replayed persistent-LSTM launches).  16-byte stores; p 16-byte aligned, n_bytes a multiple of 16.
+__global__ __launch_bounds__(256) void fill_u32_kernel(uint4* __restrict__ p, unsigned v, long n16) {
+    const uint4 w = {v, v, v, v};
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) p[i] = w;
+}
+int launch_fill_u32(void* p, unsigned value, size_t n_bytes, hipStream_t s) {
+    if ((reinterpret_cast<uintptr_t>(p) & 15) || (n_bytes & 15)) { set_error("fill: buffer must be 16-byte aligned and sized"); return -1; }
+    const long n16 = (long)(n_bytes / 16);
+    if (n16 == 0) return 0;
+    const int blocks = (int)((n16 + 255) / 256 < 2048 ? (n16 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(fill_u32_kernel, dim3(blocks), dim3(256), 0, s, static_cast<uint4*>(p), value, n16);
+    WT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_plan_guard(const unsigned* status, unsigned* host_status, int64_t* codes, long n_codes, float* f0, long n0,
                       float* f1, long n1, float* f2, long n2, hipStream_t s) {
     hipLaunchKernelGGL(plan_guard_kernel, dim3(256), dim3(256), 0, s, status, host_status, codes, n_codes, f0, n0, f1, n1, f2, n2);

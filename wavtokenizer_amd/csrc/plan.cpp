@@ -173,7 +173,7 @@ static int plan_lstm(wt_plan* P, const LstmW& w, int B, int L, int H, int xin, c
         if (persist && P->persist_ok) {
             float* hb = P->ptr(c, hx);
             static const bool counter_form = [] { const char* e = getenv("WT_LSTM_PERSIST"); return e && e[0] == '2'; }();
-            WT_HIP_CHECK(hipMemsetAsync(hb, counter_form ? 0 : 0xFF, (hxn + ctn) * sizeof(float), c.stream));
+            if (int rc = launch_fill_u32(hb, counter_form ? 0u : 0xFFFFFFFFu, (hxn + ctn) * sizeof(float), c.stream)) return rc;
             LstmPersistArgs pa;
             static const int df_trace = [] { const char* e = getenv("WT_LSTM_TRACE"); return e ? atoi(e) : 0; }();
             pa.data_flag = counter_form ? 0 : (1 | (df_trace ? 4 : 0));
@@ -183,7 +183,7 @@ static int plan_lstm(wt_plan* P, const LstmW& w, int B, int L, int H, int xin, c
             return launch_lstm_persist(pa, c.stream);
         }
         float* s = P->ptr(c, st);
-        WT_HIP_CHECK(hipMemsetAsync(s, 0, st_numel * sizeof(float), c.stream));
+        if (int rc = launch_fill_u32(s, 0u, (st_numel * sizeof(float) + 15) / 16 * 16, c.stream)) return rc;
         LstmArgs la;
         la.f16x3 = plan_fp32(P) ? 0 : 1;     // recurrent product on split-f16 MFMAs unless fp32 is forced
         la.xg0 = P->ptr(c, xg); la.W0 = la.f16x3 ? w.W0h : w.W0; la.W1 = la.f16x3 ? w.W1h : w.W1; la.b1 = w.b1;
@@ -445,7 +445,7 @@ int build_decode(wt_plan* P) {
             return gemm_s32(P, a, EPI_BIAS, OUT_S32, c.stream);
         }, 1, "attn.qk");
         P->step({h1, vt}, [=](const RunCtx& c) {     // V^T[b] = Wv . hn[b]^T + bv   (D x L, pitch Lp; pad columns stay zero)
-            WT_HIP_CHECK(hipMemsetAsync(P->ptr(c, vt), 0, (size_t)B * D * Lp * sizeof(float), c.stream));
+            if (int rc = launch_fill_u32(P->ptr(c, vt), 0u, (size_t)B * D * Lp * sizeof(float), c.stream)) return rc;
             GemmArgs a = linear_args(P->ptr(c, h1), M->at_bv, D, L, D);
             a.A = reinterpret_cast<const float*>(M->s32.at(M->at_Wv)); a.zA = 0;
             if (M->s32_acc_scale.count(M->at_Wv)) a.acc_scale = M->s32_acc_scale.at(M->at_Wv);
@@ -490,7 +490,7 @@ int build_decode(wt_plan* P) {
             return gemm_auto(P, a, PRO_NONE, EPI_BIAS, c.stream);
         });
         P->step({h1, vt}, [=](const RunCtx& c) {     // V^T[b] = Wv . hn[b]^T + bv   (D x L, pitch Lp)
-            WT_HIP_CHECK(hipMemsetAsync(P->ptr(c, vt), 0, (size_t)B * D * Lp * sizeof(float), c.stream));
+            if (int rc = launch_fill_u32(P->ptr(c, vt), 0u, (size_t)B * D * Lp * sizeof(float), c.stream)) return rc;
             GemmArgs a = linear_args(P->ptr(c, h1), M->at_bv, D, L, D);
             a.A = M->at_Wv; a.zA = 0; a.zW = (long)L * D; a.nz = B;
             a.C = P->ptr(c, vt); a.c_rstride = Lp; a.zC = (long)D * Lp;
@@ -730,8 +730,7 @@ void plan_begin(wt_plan* P) {
     P->ctl = P->buf("ctl", 64);
     const int ctl = P->ctl;
     P->step({ctl}, [=](const RunCtx& c) {
-        WT_HIP_CHECK(hipMemsetAsync(P->ptr(c, ctl), 0, 256, c.stream));
-        return 0;
+        return launch_fill_u32(P->ptr(c, ctl), 0u, 256, c.stream);
     }, 1, "ctl.clear");
 }
 

@@ -152,7 +152,10 @@ class _Engine:
 
     def __init__(self):
         self.model = ctypes.c_void_p()
-        self.max_plans = int(os.environ.get("WAVTOK_MAX_PLANS", "8"))
+        # cached plans (+ workspaces): least recently used ones go first once there are more than max_plans of them or
+        # their workspaces exceed max_ws_bytes (a file-by-file caller meets a new length, hence a new plan, per file)
+        self.max_plans = int(os.environ.get("WAVTOK_MAX_PLANS", "64"))
+        self.max_ws_bytes = int(float(os.environ.get("WAVTOK_MAX_WORKSPACE_GB", "16")) * (1 << 30))
         self.plans: Dict[Tuple[int, int, int, int], Tuple[ctypes.c_void_p, torch.Tensor]] = {}
         self.io: Dict[Tuple[int, int, int, int], Dict[str, torch.Tensor]] = {}     # fixed I/O buffers of graph plans
         self.device_index = -1
@@ -202,13 +205,15 @@ class _Engine:
         if hit is not None:
             self.plans[key] = hit                     # most recently used last (dicts keep insertion order)
             return hit
-        if len(self.plans) >= self.max_plans:         # LRU: drop the least recently used plan + workspace
-            old = next(iter(self.plans))
-            lib.wt_plan_destroy(self.plans.pop(old)[0])
-            self.io.pop(old, None)
         p = ctypes.c_void_p()
         check(lib.wt_plan_create(self.model, kind, B, length, flags, ctypes.byref(p)), "wt_plan_create")
-        ws = torch.empty(lib.wt_plan_workspace_bytes(p), dtype=torch.uint8, device=device)
+        need = lib.wt_plan_workspace_bytes(p)
+        while self.plans and (len(self.plans) >= self.max_plans or
+                              sum(w.numel() for _p, w in self.plans.values()) + need > self.max_ws_bytes):
+            old = next(iter(self.plans))              # LRU: the least recently used plan + workspace
+            lib.wt_plan_destroy(self.plans.pop(old)[0])
+            self.io.pop(old, None)
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
         self.plans[key] = (p, ws)
         return p, ws
 
