@@ -197,7 +197,7 @@ int wt_sconv1d(const float* x, const float* w, const float* bias, float* y, int3
  * pre-split "S32" operands staged by LDS-DMA (gemm16s.hip: the plans' producers write S32 directly; here x and w
  * are split into the workspace first, 4*(M+N)*K bytes, K % 32 == 0); 3: as 2 and y is written in S32 too
  * (N % 32 == 0; every 32 outputs of a row = 128 bytes [32 x f16 hi | 32 x f16 lo], value = hi + lo * 2^-11).
- * Modes 2 / 3 need 256 more bytes of workspace (per-tensor scales). */
+ * Modes 2 / 3 need 8 KB more workspace (per-tensor scales; clock stamps of the timing-experiment builds). */
 int wt_linear(const float* x, const float* w, const float* bias, float* y, int64_t M, int32_t N, int32_t K,
               int32_t f16x3, void* workspace, void* stream);
 

@@ -2,6 +2,12 @@
 
   linear_overlap_add  — restates encoder/utils.py:17-56 (`_linear_overlap_add`).  PINNED: tests/golden/overlap_add.npz
                         holds outputs of the reference function itself (tests/golden/make_golden_audio.py imports it).
+  segmented_round_trip — restates EncodecModel.forward's segment loop (encoder/model.py:122-145 `encode`: frames at offsets
+                        range(0, length, stride) of segment_length samples; :167-178 `decode`: every frame decoded, then
+                        `_linear_overlap_add(frames, stride)`; :189-191 `forward`: trimmed to the input length) around the
+                        WavTokenizer codec path (oracle/cpu_ref.py `encode_infer` / `decode` in place of EncodecModel's
+                        `_encode_frame` / `_decode_frame`, which WavTokenizer never calls).  Pinned through its parts: the
+                        codec oracle by the reference fixtures, the overlap-add by overlap_add.npz.
   convert_audio       — restates encoder/utils.py:79-92: channel mix, then `torchaudio.transforms.Resample(sr, target_sr)`.
                         PARITY UNPINNED for the resampler: torchaudio (the reference pins no version; requirements.txt
                         lists `torchaudio`) is absent from this image and the reference holds no fixture for it.  The
@@ -95,3 +101,18 @@ def to_pcm16(wav, rescale=False, limit=0.99):
     else:
         wav = np.clip(wav, -limit, limit)
     return np.clip(np.rint(wav.astype(np.float32) * np.float32(32768.0)), -32768, 32767).astype(np.int16)
+
+
+def segmented_round_trip(oracle_model, wav, segment_length, stride, bandwidth_id=None):
+    """wav: torch tensor [B, T] -> numpy [B, T]: encoder/model.py:139-145 (frame offsets), :174-178 (decode every frame,
+    linear overlap-add) and :191 (trim to the input length), with the WavTokenizer oracle as the codec."""
+    import torch
+    bw = bandwidth_id if bandwidth_id is not None else torch.tensor([0])
+    length = wav.shape[-1]
+    frames = []
+    with torch.inference_mode():
+        for offset in range(0, length, stride):
+            frame = wav[..., offset: offset + segment_length]
+            feats, _codes = oracle_model.encode_infer(frame, bw)
+            frames.append(oracle_model.decode(feats, bw)[..., : frame.shape[-1]].numpy())
+    return linear_overlap_add(frames, stride)[..., :length]

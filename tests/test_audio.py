@@ -102,5 +102,17 @@ def test_segmented_round_trip():
     whole = m.decode(m.encode_infer(wav, bandwidth_id=bw)[0], bandwidth_id=bw)[..., :48000]
     one = audio.segmented_round_trip(m, wav, 48000, 48000)            # a single segment: weights cancel exactly
     assert one.shape == wav.shape and torch.allclose(one, whole, rtol=0, atol=1e-6)
-    seg = audio.segmented_round_trip(m, wav, 24000, 18000)            # 3 overlapping segments
-    assert seg.shape == wav.shape and torch.isfinite(seg).all()
+    # overlapping segments against the restated reference loop (encoder/model.py:122-190): 3 segments of 1 s at a 0.75 s
+    # stride (the last one ragged), and 4 segments whose length is not a multiple of the hop
+    from oracle import audio_ref
+    from oracle.cpu_ref import OracleWavTokenizer
+    from tests.util import rel_l2, WAV_REL_TOL
+    from tests import parity_log
+    orc = OracleWavTokenizer(arch, synth_state_dict("hop600"))
+    for seg_len, stride in ((24000, 18000), (17777, 11111)):
+        got = audio.segmented_round_trip(m, wav, seg_len, stride)
+        want = audio_ref.segmented_round_trip(orc, wav.cpu(), seg_len, stride)
+        assert got.shape == wav.shape == want.shape
+        err = rel_l2(got.cpu().numpy(), want)
+        parity_log.record(f"segmented_round_trip[{seg_len},{stride}]", wav_rel_l2=err)
+        assert err < WAV_REL_TOL, (seg_len, stride, err)

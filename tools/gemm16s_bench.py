@@ -42,7 +42,7 @@ def main():
         w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
         b = torch.randn(N, generator=g).cuda()
         y = torch.zeros(M, N, device="cuda")
-        ws = torch.empty(4 * (N + M) * K + 1024, dtype=torch.uint8, device="cuda")
+        ws = torch.zeros(4 * (N + M) * K + 8192, dtype=torch.uint8, device="cuda")
         if tile is not None:
             os.environ["WT_GEMM16S_TILE"] = str(tile)
         else:
@@ -50,6 +50,13 @@ def main():
         for _ in range(WARM + REPS):
             check(lib.wt_linear(ptr(x), ptr(w), ptr(b), ptr(y), M, N, K, mode, ptr(ws), None), "wt_linear")
         torch.cuda.synchronize()
+        if os.environ.get("WT_GEMM16S_DBG"):      # in-kernel clock of the timing-experiment builds: d(s_memtime) / d(s_memrealtime) x 100 MHz
+            st = ws[4 * (N + M) * K + 256: 4 * (N + M) * K + 256 + 4096].view(torch.int64).view(256, 2).cpu().double()
+            ok = st[:, 1] > 0
+            if ok.any():
+                ghz = (st[ok, 0] / st[ok, 1] * 0.1).median().item()
+                print(f"   in-kernel clock (median over {int(ok.sum())} workgroups): {ghz:.3f} GHz", flush=True)
+                label = f"{label} [{ghz:.2f} GHz]"
         out = decode_s32(y, M, N) if mode == 3 else y
         ref = x[:1024].double() @ w.double().t() + b.double()
         err = ((out[:1024].double() - ref).norm() / ref.norm()).item()
@@ -96,11 +103,14 @@ def main():
         json.dump(calls, open(sys.argv[1], "w"))
         return
     if len(sys.argv) > 2 and sys.argv[2] == "dbg":
-        for dbg, dn in ((0, "full"), (5, "no DMA/epi"), (5 + 8, "no DMA/epi/barrier"), (5 + 16, "no DMA/epi/ds_read"), (5 + 8 + 16 + 32, "MFMA only"),
-                        (5 + 8 + 32, "no DMA/epi/barrier/wait"), (4 + 2, "DMA + reads + barrier")):
-            os.environ["WT_GEMM16S_DBG"] = str(dbg)
-            linear(f"pwconv1 s32 128x192x3 {dn}", 7680, 2304, 768, 2, 2)
-            os.environ.pop("WT_GEMM16S_DBG")
+        WARM, REPS = 30, 40             # long enough for the chip to settle at the clock it holds under this load
+        for mode, mn in ((2, "bias -> fp32"),):
+            linear(f"pwconv1 {mn} shipped build", 7680, 2304, 768, mode, 2)
+            for dbg, dn in ((1024, "full (stamped)"), (4, "no epilogue"), (5, "no epilogue, no DMA"), (13, "no epilogue, no DMA, no barrier"),
+                            (45, "MFMA + LDS fragment reads"), (61, "MFMA only"), (21, "no epilogue, no DMA, no LDS reads"), (64, "full, younger half at priority 1")):
+                os.environ["WT_GEMM16S_DBG"] = str(dbg)
+                linear(f"pwconv1 {mn}: {dn}", 7680, 2304, 768, mode, 2)
+                os.environ.pop("WT_GEMM16S_DBG")
         json.dump(calls, open(sys.argv[1], "w"))
         return
     if len(sys.argv) > 2 and sys.argv[2] == "tune":
@@ -110,10 +120,7 @@ def main():
             os.environ["WT_GEMM16S_NONPERSISTENT"] = "1"
             linear(f"{name} s32 128x192x3 non-persistent", M, N, K, 2, 2)
             os.environ.pop("WT_GEMM16S_NONPERSISTENT")
-            for dbg, dn in ((64, "setprio younger half"), (1, "no DMA"), (2, "no MFMA"), (4, "no epilogue"), (5, "no DMA, no epilogue"), (6, "DMA only")):
-                os.environ["WT_GEMM16S_DBG"] = str(dbg)
-                linear(f"{name} s32 128x192x3 {dn}", M, N, K, 2, 2)
-                os.environ.pop("WT_GEMM16S_DBG")
+
         json.dump(calls, open(sys.argv[1], "w"))
         return
     shapes = [("pwconv1", 7680, 2304, 768), ("pwconv2", 7680, 768, 2304), ("head", 7680, 2432, 768),

@@ -396,6 +396,8 @@ int wt_linear(const float* x, const float* w, const float* bias, float* y, int64
     }
     char* xs = hi + (size_t)N * K * 4;
     if (int rc = split_pair(w, (long)N * K, x, (long)M * K, hi, xs, xs + (size_t)M * K * 4, a, s)) return rc;
+    // timing-experiment builds (WT_GEMM16S_DBG: tools/gemm16s_bench.py) leave their clock stamps behind the scales
+    a.dbg_stamps = reinterpret_cast<unsigned long long*>(xs + (size_t)M * K * 4 + 256);
     return launch_gemm16s(a, EPI_BIAS, f16x3 == 3 ? 1 : 0, s);
 }
 

@@ -139,7 +139,7 @@ struct GemmArgs {
     float acc_scale = 1.f;                 // gemm16s: the accumulators are multiplied by this (a power of two: operands were
     const float* acc_scale_dev = nullptr;  // stored scaled) before bias / activation; the device copy, when set, wins
     unsigned* status = nullptr;            // gemm16s: call status word (range report of the S32 epilogues); launcher default: g_launch
-    int dbg = 0;          // gemm16s timing experiments only (WT_GEMM16S_DBG): 1 no DMA in the K loop, 2 no MFMA, 4 no epilogue
+    unsigned long long* dbg_stamps = nullptr;   // gemm16s timing-experiment builds: per workgroup {s_memtime, s_memrealtime} spans
 };
 
 int gemm_vq_parts(int N);   // partial (val, idx) slots per row written by EPI_ARGMAX

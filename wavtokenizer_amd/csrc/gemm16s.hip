@@ -18,6 +18,7 @@
 
 #include <cmath>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace wt {
 
@@ -111,8 +112,18 @@ __device__ __forceinline__ void wait_vm_lgkm() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int EPI, int OUT>
+// DBG: timing-experiment builds (WT_GEMM16S_DBG, tools/gemm16s_bench.py): a compile-time mask of phases to leave out
+// (1 DMA, 2 MFMA, 4 epilogue, 8 barrier, 16 LDS fragment reads, 32 waits, 64 static priority for the younger half, 128
+// stores, 256 bias, 512 GELU; 1024: stamp s_memtime / s_memrealtime around the tile loop into GemmArgs::dbg_stamps: the
+// clock the chip holds).  The shipped instantiations have DBG = 0.  The mask is a template argument because a run-time
+// test in front of every phase (round 1) cuts the K loop and the epilogue into dozens of basic blocks, across which
+// hipcc neither overlaps LDS reads with MFMAs nor one 4-column run's GELU with the next one's: 108.7 -> 102.7 us on pwconv1.
+#ifndef WT_GEMM16S_MF
+#define WT_GEMM16S_MF 1          // MFMA shape of every instantiation (0: 32x32x16, for A/B timing builds; 1: 16x16x32)
+#endif
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int EPI, int OUT, int DBG = 0, int MF = WT_GEMM16S_MF>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(const GemmArgs p) {
+    constexpr int dbg = DBG;
     constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -263,19 +274,32 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
         }
     };
 
-    // fragment (v_mfma_f32_32x32x16_f16): lane (r = lane & 31, h = lane >> 5) holds k = 16 s + 8 h .. + 7 of row r:
-    // logical chunk 2 s + h of the hi half, 4 + 2 s + h of the lo half
+    // Two MFMA shapes (template argument MF):
+    //   MF = 0  v_mfma_f32_32x32x16_f16: lane (r = lane & 31, h = lane >> 5) holds k = 16 s + 8 h .. + 7 of row r: logical
+    //           chunk 2 s + h of the hi half, 4 + 2 s + h of the lo half; a K step is two 16-deep halves
+    //   MF = 1  v_mfma_f32_16x16x32_f16 (the default): lane (r = lane & 15, q = lane >> 4) holds k = 8 q .. 8 q + 7 of row r:
+    //           chunk q of the hi half, 4 + q of the lo half; a K step is ONE 32-deep MFMA per 16 x 16 tile.  Same LDS
+    //           image, same reads per step (16 ds_read_b128 per wave), conflict-free under the same swizzle, same
+    //           accumulator count.  The chip holds a higher clock on this shape for the same work: the bare MFMA + LDS
+    //           loop of this kernel ran 215 vs 245 us per unit of work at 1.82 vs 1.56 GHz (tools/micro/mfma_shape.hip).
     const int frow = (lane & 31) * 128, fsw = ((lane & 31) >> 1) & 7, fh = lane >> 5;
     int fo[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) fo[c] = frow + (((2 * c + fh) ^ fsw) * 16);
+    const int r16 = lane & 15, q4 = lane >> 4;
+    // 16-row tiles start at multiples of 16 rows, so the swizzle term (row >> 1) & 7 depends on r16 alone
+    const int fo16h = r16 * 128 + ((q4 ^ ((r16 >> 1) & 7)) * 16), fo16l = r16 * 128 + (((4 + q4) ^ ((r16 >> 1) & 7)) * 16);
     const int offA = wm * WM * 128, offB = (BM + wn * WN) * 128;
 
     // Operand order: the weight fragment is the MFMA's A operand and the activation fragment its B operand, so the
-    // accumulator comes out transposed: lane -> output ROW (m = lane & 31), registers -> 4-column runs
-    // n = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  The epilogue then moves 16 bytes (fp32) or 8 + 8 bytes (S32) per
-    // lane and store, and bias / gamma are per-register vectors.
-    f32x16 accm[TM][TN], accc[TM][TN];
+    // accumulator comes out transposed: lane -> output ROW, registers -> 4-column runs.  A 32 x 32 block of the wave tile
+    // is four "sub-runs" s = 0..3 of 4 columns per lane:
+    //   MF = 0: row = lane & 31,               col = 8 s + 4 (lane >> 5)          (registers 4 s .. 4 s + 3 of the 32x32 tile)
+    //   MF = 1: row = 16 (s >> 1) + (lane & 15), col = 16 (s & 1) + 4 (lane >> 4)   (the 16x16 tile (s >> 1, s & 1) of the block)
+    // The epilogue then moves 16 bytes (fp32) or 8 + 8 bytes (S32) per lane and store, and bias / gamma are per-register vectors.
+    constexpr int TM16 = WM / 16, TN16 = WN / 16, TNH = TN16 / 2;
+    f32x16 accm[MF ? 1 : TM][MF ? 1 : TN], accc[MF ? 1 : TM][MF ? 1 : TN];
+    f32x4 am[MF ? TM16 : 1][MF ? TN16 : 1], ac[MF ? TM16 : 1][MF ? TN16 : 1];
     struct Frags { f16x8 ah[TM], al[TM], bh[TN], bl[TN]; };
     auto read_frags = [&](int stage, int s, Frags& F) {
         const char* sA = smem_s + stage * STG + offA;
@@ -296,9 +320,43 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.bh[j], F.ah[i], accm[i][j], 0, 0, 0);
-                accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.bl[j], F.ah[i], accc[i][j], 0, 0, 0);
-                accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.bh[j], F.al[i], accc[i][j], 0, 0, 0);
+                accm[MF ? 0 : i][MF ? 0 : j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.bh[j], F.ah[i], accm[MF ? 0 : i][MF ? 0 : j], 0, 0, 0);
+                accc[MF ? 0 : i][MF ? 0 : j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.bl[j], F.ah[i], accc[MF ? 0 : i][MF ? 0 : j], 0, 0, 0);
+                accc[MF ? 0 : i][MF ? 0 : j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.bh[j], F.al[i], accc[MF ? 0 : i][MF ? 0 : j], 0, 0, 0);
+            }
+    };
+    // MF = 1: the activation fragments of a step (all TM16 row tiles) and the weight fragments in two halves of TNH column tiles
+    struct FragA { f16x8 h[TM16], l[TM16]; };
+    struct FragB { f16x8 h[TNH], l[TNH]; };
+    auto read_a16 = [&](int stage, FragA& F) {
+        const char* sA = smem_s + stage * STG + offA;
+#pragma unroll
+        for (int i = 0; i < TM16; ++i) {
+            F.h[i] = *reinterpret_cast<const f16x8*>(sA + i * 16 * 128 + fo16h);
+            F.l[i] = *reinterpret_cast<const f16x8*>(sA + i * 16 * 128 + fo16l);
+        }
+    };
+    auto read_b16 = [&](int stage, int half, FragB& F) {
+        const char* sB = smem_s + stage * STG + offB + half * TNH * 16 * 128;
+#pragma unroll
+        for (int j = 0; j < TNH; ++j) {
+            F.h[j] = *reinterpret_cast<const f16x8*>(sB + j * 16 * 128 + fo16h);
+            F.l[j] = *reinterpret_cast<const f16x8*>(sB + j * 16 * 128 + fo16l);
+        }
+    };
+    auto mfma16_block = [&](const FragA& A, const FragB& Bf, auto half_c) {
+        constexpr int half = decltype(half_c)::value;          // a constant: the accumulators must stay in registers
+#pragma unroll
+        for (int jj = 0; jj < TNH; ++jj)
+#pragma unroll
+            for (int i = 0; i < TM16; ++i) {
+                constexpr int jbase = half * TNH;
+                const int j = jbase + jj;
+                f32x4& m = am[MF ? i : 0][MF ? j : 0];
+                f32x4& c = ac[MF ? i : 0][MF ? j : 0];
+                m = __builtin_amdgcn_mfma_f32_16x16x32_f16(Bf.h[jj], A.h[i], m, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Bf.l[jj], A.h[i], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Bf.h[jj], A.l[i], c, 0, 0, 0);
             }
     };
 
@@ -310,6 +368,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
     //            and for its LDS reads, then the barrier makes that tile visible to everyone
     //   bottom : read the first-half fragments of the next K tile, MFMAs on the second half of this one
     // so no wave sits behind a barrier with nothing to issue: fragments always arrive under the other half's MFMAs.
+    // (MF = 0: the halves are the two 16-deep k halves of the step.  MF = 1: the halves are the first and the last TNH
+    // weight column tiles; the activation fragments serve both halves, so the next step's are read last in the bottom
+    // phase, into the registers the second half's MFMAs have just read.)
     // The stream does not stop at an output-tile boundary: the first K tiles of the workgroup's next output tile are
     // already landing while the last steps of this one run, its first fragments are read before the epilogue, and
     // the epilogue's own loads and stores simply queue behind them.  Past the last tile the DMAs are issued all the
@@ -320,7 +381,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
     // accumulators are brought back by acc_s, exactly (a power of two), before bias and activation
     const float acc_s = p.acc_scale_dev ? *p.acc_scale_dev : p.acc_scale;
     const float lo_s = acc_s * (1.f / 2048.f);
-    if ((p.dbg & 64) && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);     // experiment: static priority for the younger half
+    if ((dbg & 64) && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);     // experiment: static priority for the younger half
+    unsigned long long st_c0 = 0, st_r0 = 0;
+    if (dbg & 1024) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
     build_table(blockIdx.x, 0);
     __syncthreads();
     loader_set_tile(blockIdx.x, 0);
@@ -329,7 +392,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
     wait_vm_lgkm<(NSTAGE - 2) * NPT>();
     __builtin_amdgcn_s_barrier();
     Frags F0, F1;
-    read_frags(0, 0, F0);
+    FragA Fa;
+    FragB F0b, F1b;
+    if (MF) { read_a16(0, Fa); read_b16(0, 0, F0b); }
+    else read_frags(0, 0, F0);
     int rs = 0, ws = NSTAGE - 1;
     int c_par = 0;
     for (int vb = blockIdx.x; vb < ntiles; vb += G, c_par ^= 1) {
@@ -348,83 +414,137 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
             if (p.bias) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBias, (lds_ptr_t)pc, 16, nb4, 0, 0, 0);
             if (EPI == EPI_BIAS_GAMMA_RES) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsGamma, (lds_ptr_t)(pc + WN * 4), 16, nb4, 0, 0, 0);
         }
+        if (MF) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM16; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN16; ++j) { am[MF ? i : 0][MF ? j : 0] = (f32x4){0.f, 0.f, 0.f, 0.f}; ac[MF ? i : 0][MF ? j : 0] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { accm[i][j][r] = 0.f; accc[i][j][r] = 0.f; }
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { accm[MF ? 0 : i][MF ? 0 : j][r] = 0.f; accc[MF ? 0 : i][MF ? 0 : j][r] = 0.f; }
+        }
         for (int kt = 0; kt < nk; ++kt) {
-            if (!(p.dbg & 1)) load_tile(ws);
-            if (!(p.dbg & 16)) read_frags(rs, 1, F1);
-            if (!(p.dbg & 2)) mfma_block(F0);
-            if (!(p.dbg & 32)) wait_vm_lgkm<(NSTAGE - 2) * NPT>();
-            if (!(p.dbg & 8)) __builtin_amdgcn_s_barrier();
+            if (!(dbg & 1)) load_tile(ws);
+            if (MF) {
+                if (!(dbg & 16)) read_b16(rs, 1, F1b);
+                if (!(dbg & 2)) mfma16_block(Fa, F0b, std::integral_constant<int, 0>{});
+            } else {
+                if (!(dbg & 16)) read_frags(rs, 1, F1);
+                if (!(dbg & 2)) mfma_block(F0);
+            }
+            if (!(dbg & 32)) wait_vm_lgkm<(NSTAGE - 2) * NPT>();
+            if (!(dbg & 8)) __builtin_amdgcn_s_barrier();
             rs = rs + 1 == NSTAGE ? 0 : rs + 1;
             ws = ws + 1 == NSTAGE ? 0 : ws + 1;
-            if (!(p.dbg & 16)) read_frags(rs, 0, F0);          // after the very last step: a harmless read of a zero-filled stage
-            if (!(p.dbg & 2)) mfma_block(F1);
+            if (MF) {
+                if (!(dbg & 16)) read_b16(rs, 0, F0b);       // after the very last step: a harmless read of a zero-filled stage
+                if (!(dbg & 2)) mfma16_block(Fa, F1b, std::integral_constant<int, 1>{});
+                if (!(dbg & 16)) read_a16(rs, Fa);
+            } else {
+                if (!(dbg & 16)) read_frags(rs, 0, F0);
+                if (!(dbg & 2)) mfma_block(F1);
+            }
         }
-        if (p.dbg & 4) continue;
+        if (dbg & 4) {      // timing builds without an epilogue: keep the accumulators (and so the MFMAs) alive through
+                            // a store the compiler cannot rule out (alpha is never this value)
+            if (p.alpha == -12345.f) {
+                if (MF) {
+#pragma unroll
+                    for (int i = 0; i < TM16; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN16; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) p.C[(tid * 4 + r) * 2] = am[MF ? i : 0][MF ? j : 0][r] + ac[MF ? i : 0][MF ? j : 0][r];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) p.C[(tid * 16 + r) * 2] = accm[MF ? 0 : i][MF ? 0 : j][r] + accc[MF ? 0 : i][MF ? 0 : j][r];
+                }
+            }
+            continue;
+        }
 
     // ------------------------------------------------------------------------- epilogue
-    const int row_l = lane & 31, col_h = 4 * (lane >> 5);
     const int m_w = bm * BM + wm * WM, n_w = bn * BN + wn * WN;
     float* __restrict__ Cg = p.C + (long)z * p.zC;
-    auto acc4 = [&](int i, int j, int g) {
+    // sub-run s of a 32 x 32 block: its row and first column inside the block (see the accumulator layouts above)
+    auto sub_row = [&](int s) { return MF ? 16 * (s >> 1) + r16 : (lane & 31); };
+    auto sub_col = [&](int s) { return MF ? 16 * (s & 1) + 4 * q4 : 8 * s + 4 * (lane >> 5); };
+    auto acc4 = [&](int i, int j, int s) {
         f32x4 v;
-        v.x = fmaf(accc[i][j][4 * g + 0], lo_s, accm[i][j][4 * g + 0] * acc_s);
-        v.y = fmaf(accc[i][j][4 * g + 1], lo_s, accm[i][j][4 * g + 1] * acc_s);
-        v.z = fmaf(accc[i][j][4 * g + 2], lo_s, accm[i][j][4 * g + 2] * acc_s);
-        v.w = fmaf(accc[i][j][4 * g + 3], lo_s, accm[i][j][4 * g + 3] * acc_s);
+        if (MF) {
+            const f32x4 m = am[MF ? 2 * i + (s >> 1) : 0][MF ? 2 * j + (s & 1) : 0], c = ac[MF ? 2 * i + (s >> 1) : 0][MF ? 2 * j + (s & 1) : 0];
+            v.x = fmaf(c.x, lo_s, m.x * acc_s);
+            v.y = fmaf(c.y, lo_s, m.y * acc_s);
+            v.z = fmaf(c.z, lo_s, m.z * acc_s);
+            v.w = fmaf(c.w, lo_s, m.w * acc_s);
+        } else {
+            v.x = fmaf(accc[MF ? 0 : i][MF ? 0 : j][4 * s + 0], lo_s, accm[MF ? 0 : i][MF ? 0 : j][4 * s + 0] * acc_s);
+            v.y = fmaf(accc[MF ? 0 : i][MF ? 0 : j][4 * s + 1], lo_s, accm[MF ? 0 : i][MF ? 0 : j][4 * s + 1] * acc_s);
+            v.z = fmaf(accc[MF ? 0 : i][MF ? 0 : j][4 * s + 2], lo_s, accm[MF ? 0 : i][MF ? 0 : j][4 * s + 2] * acc_s);
+            v.w = fmaf(accc[MF ? 0 : i][MF ? 0 : j][4 * s + 3], lo_s, accm[MF ? 0 : i][MF ? 0 : j][4 * s + 3] * acc_s);
+        }
         return v;
     };
 
     if constexpr (EPI == EPI_ARGMAX) {
         // VQ (core_vq.py:176-182): per row, the best of this wave's WN columns of -(|x|^2 - 2 x.e + |e|^2), lowest
-        // index on ties; a lane holds one row (and its partner lane + 32 the other half of the columns)
+        // index on ties.  MF = 0: a lane holds one row, its partner lane + 32 the other half of the columns.  MF = 1: a
+        // lane holds two rows (16 apart), and the four lanes r16, r16 + 16, + 32, + 48 share a row's columns.
         const int part = bn * WAVES_N + wn;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m_w + i * 32 + row_l;
-            const float xx = (m < p.M) ? p.vq_xx[m] : 0.f;
-            float best = -INFINITY;
-            int bidx = 0x7fffffff;
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int rsel = 0; rsel < (MF ? 2 : 1); ++rsel) {
+                const int m = m_w + i * 32 + (MF ? 16 * rsel + r16 : (lane & 31));
+                const float xx = (m < p.M) ? p.vq_xx[m] : 0.f;
+                float best = -INFINITY;
+                int bidx = 0x7fffffff;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n = n_w + j * 32 + 8 * g + col_h;
-                    if (n >= p.N) continue;
-                    const f32x4 dot = acc4(i, j, g);
-                    const f32x4 ee = *reinterpret_cast<const f32x4*>(p.vq_ee + n);
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float d = -((xx - 2.f * dot[e]) + ee[e]);
-                        if (d > best) { best = d; bidx = n + e; }        // ascending n within the lane: strict > keeps the lowest
+                    for (int ss = 0; ss < (MF ? 2 : 4); ++ss) {
+                        const int s = MF ? 2 * rsel + ss : ss;          // ascending columns within the lane either way
+                        const int n = n_w + j * 32 + sub_col(s);
+                        if (n >= p.N) continue;
+                        const f32x4 dot = acc4(i, j, s);
+                        const f32x4 ee = *reinterpret_cast<const f32x4*>(p.vq_ee + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float d = -((xx - 2.f * dot[e]) + ee[e]);
+                            if (d > best) { best = d; bidx = n + e; }        // ascending n within the lane: strict > keeps the lowest
+                        }
                     }
+#pragma unroll
+                for (int off = (MF ? 16 : 32); off <= 32; off <<= 1) {
+                    const float ov = __shfl_xor(best, off, 64);
+                    const int oi = __shfl_xor(bidx, off, 64);
+                    if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
                 }
-            const float ov = __shfl_xor(best, 32, 64);
-            const int oi = __shfl_xor(bidx, 32, 64);
-            if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-            if (lane < 32 && m < p.M) {
-                p.vq_pval[(long)m * p.vq_nparts + part] = best;
-                p.vq_pidx[(long)m * p.vq_nparts + part] = bidx;
+                if ((MF ? q4 == 0 : lane < 32) && m < p.M) {
+                    p.vq_pval[(long)m * p.vq_nparts + part] = best;
+                    p.vq_pidx[(long)m * p.vq_nparts + part] = bidx;
+                }
             }
-        }
     } else if constexpr (EPI == EPI_HEAD) {
         static_assert(TN % 2 == 0, "head epilogue pairs column tiles");
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int m = m_w + i * 32 + row_l;
-            if (m >= p.M) continue;
-            float* crow = Cg + (long)m * p.c_rstride;
 #pragma unroll
             for (int j = 0; j + 1 < TN; j += 2)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int pc = n_w + j * 32 + 8 * g + col_h;      // packed row of the log-magnitude; phase 32 later
-                    if (pc >= p.N) continue;
+                    const int m = m_w + i * 32 + sub_row(g);
+                    const int pc = n_w + j * 32 + sub_col(g);         // packed row of the log-magnitude; phase 32 later
+                    if (m >= p.M || pc >= p.N) continue;
+                    float* crow = Cg + (long)m * p.c_rstride;
                     const f32x4 bmag = *reinterpret_cast<const f32x4*>(p.bias + pc);
                     const f32x4 bph = *reinterpret_cast<const f32x4*>(p.bias + pc + 32);
                     const f32x4 lm = acc4(i, j, g) + bmag, ph = acc4(i, j + 1, g) + bph;
@@ -457,7 +577,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
                                    (OUT == OUT_S32 && (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ELU));
         if (CAN_STAGE && p.stage_epi) {
             char* sc = smem_s + p.stage_off + wave * 4096;
-            const int sw_w = (row_l >> 1) & 7;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -472,15 +591,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
                         f32x4 bq[4];
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            const int n = n0 + 8 * g + col_h;
+                            const int n = n0 + sub_col(g);
                             bq[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                            if (p.bias && n < p.N && !(p.dbg & 256))
+                            if (p.bias && n < p.N && !(dbg & 256))
                                 bq[g] = PCACHE ? *reinterpret_cast<const f32x4*>(pcw + (n - n_w) * 4) : *reinterpret_cast<const f32x4*>(p.bias + n);
                         }
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
+                            const int rw = sub_row(g), cw = sub_col(g), sww = (rw >> 1) & 7;
                             f32x4 v = acc4(i, j, g) + bq[g];
-                            if (EPI == EPI_BIAS_GELU && (p.dbg & 512)) {
+                            if (EPI == EPI_BIAS_GELU && (dbg & 512)) {
                             } else
                             if (EPI == EPI_BIAS_ELU || (OUT == OUT_S32_DUAL_ELU && pz == 1)) {
                                 v.x = elu_s(v.x); v.y = elu_s(v.y); v.z = elu_s(v.z); v.w = elu_s(v.w);
@@ -488,16 +608,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
                                 v = gelu_erf_s4(v);
                             }
                             if (as_f32) {
-                                const int ch = 2 * g + (col_h >> 2);
-                                *reinterpret_cast<f32x4*>(sc + row_l * 128 + ((ch ^ sw_w) * 16)) = v;
+                                *reinterpret_cast<f32x4*>(sc + rw * 128 + (((cw >> 2) ^ sww) * 16)) = v;
                             } else {
                                 amax = amax4(amax, v.x, v.y, v.z, v.w);
                                 f16x4 hi, lo;
                                 hi.x = (_Float16)v.x; hi.y = (_Float16)v.y; hi.z = (_Float16)v.z; hi.w = (_Float16)v.w;
                                 lo.x = (_Float16)((v.x - (float)hi.x) * 2048.f); lo.y = (_Float16)((v.y - (float)hi.y) * 2048.f);
                                 lo.z = (_Float16)((v.z - (float)hi.z) * 2048.f); lo.w = (_Float16)((v.w - (float)hi.w) * 2048.f);
-                                *reinterpret_cast<f16x4*>(sc + row_l * 128 + ((g ^ sw_w) * 16) + 2 * col_h) = hi;
-                                *reinterpret_cast<f16x4*>(sc + row_l * 128 + (((4 + g) ^ sw_w) * 16) + 2 * col_h) = lo;
+                                *reinterpret_cast<f16x4*>(sc + rw * 128 + (((cw >> 3) ^ sww) * 16) + 2 * (cw & 7)) = hi;
+                                *reinterpret_cast<f16x4*>(sc + rw * 128 + (((4 + (cw >> 3)) ^ sww) * 16) + 2 * (cw & 7)) = lo;
                             }
                         }
                         // a wave's LDS operations execute in order and the scratch is private to the wave: no barrier
@@ -514,7 +633,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
                             const int r = 8 * it + (lane >> 3), ch = lane & 7;
                             const int m = m_w + i * 32 + r;
                             const int n = n0 + 4 * ch;             // fp32 columns; S32: byte ch * 16 of the group at n0
-                            if (m < p.M && (!as_f32 || n < p.N) && !(p.dbg & 128)) {
+                            if (m < p.M && (!as_f32 || n < p.N) && !(dbg & 128)) {
                                 float* dst = dbase + (long)m * p.c_rstride + n;
                                 *reinterpret_cast<f32x4*>(dst) = q[it];
                             }
@@ -525,15 +644,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
         } else
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int m = m_w + i * 32 + row_l;
-            if (m >= p.M) continue;
-            float* crow = Cg + (long)m * p.c_rstride;
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int n = n_w + j * 32 + 8 * g + col_h;        // columns n .. n+3 (N % 4 == 0)
-                    if (n >= p.N) continue;
+                    const int m = m_w + i * 32 + sub_row(g);
+                    const int n = n_w + j * 32 + sub_col(g);        // columns n .. n+3 (N % 4 == 0)
+                    if (m >= p.M || n >= p.N) continue;
+                    float* crow = Cg + (long)m * p.c_rstride;
                     f32x4 v = acc4(i, j, g);
                     if (EPI == EPI_SCALE || EPI == EPI_BIAS_ROW) {
                         v = EPI == EPI_SCALE ? v * p.alpha : v + p.bias[m];
@@ -568,6 +686,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
         }
     }
     }   // persistent tile loop
+    if ((dbg & 1024) && p.dbg_stamps && tid == 0) {
+        p.dbg_stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st_c0;
+        p.dbg_stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+    }
     range_report(p.status, amax);
     wait_vm_lgkm<0>();
 }
@@ -641,10 +763,35 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
     constexpr size_t smem_max = smem_want < smem_cap ? smem_want : smem_cap;
     static_assert(stage_bytes + 2 * BM * sizeof(unsigned) <= smem_cap, "LDS budget");
     if (smem > smem_cap) { set_error("gemm16s: too many taps for this tile's LDS budget"); return -1; }
-    auto kern = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT>;
+    using kern_t = void (*)(const GemmArgs);
+    kern_t kern = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT>;
+    // the timing-experiment builds exist for the tile the ConvNeXt GEMMs run on (tools/gemm16s_bench.py dbg): the masks of
+    // the ablation ladder, each also with the clock stamps (+1024)
+    constexpr bool has_dbg = BM == 128 && BN == 192 && WMs == 4 && NSTAGE == 3 && ((EPI == EPI_BIAS && OUT == OUT_F32) || (EPI == EPI_BIAS_GELU && OUT == OUT_S32));
+    int dbg_req = 0;
+    if (const char* e = getenv("WT_GEMM16S_DBG")) dbg_req = atoi(e);
+    kern_t dbg_kerns[8] = {};
+    static constexpr int dbg_masks[8] = {1024, 1024 + 4, 1024 + 5, 1024 + 13, 1024 + 45, 1024 + 61, 1024 + 64, 1024 + 21};
+    if constexpr (has_dbg) {
+        dbg_kerns[0] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024>;
+        dbg_kerns[1] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024 + 4>;
+        dbg_kerns[2] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024 + 5>;
+        dbg_kerns[3] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024 + 13>;
+        dbg_kerns[4] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024 + 45>;
+        dbg_kerns[5] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024 + 61>;
+        dbg_kerns[6] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024 + 64>;
+        dbg_kerns[7] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024 + 21>;
+        if (dbg_req) {
+            kern = nullptr;
+            for (int i = 0; i < 8; ++i) if (dbg_masks[i] == (dbg_req | 1024)) kern = dbg_kerns[i];
+            if (!kern) { set_error("gemm16s: no timing-experiment build for this WT_GEMM16S_DBG mask"); return -1; }
+        }
+    }
     if (int rc = attr_once.run([&]() -> int {
-        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)smem_max));
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max));
+        for (int i = 0; i < 8; ++i)
+            if (dbg_kerns[i]) WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dbg_kerns[i]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max));
         return 0;
     })) return rc;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
@@ -681,7 +828,6 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
             smem = off + (size_t)WMs * WNs * 4096;
         }
     }
-    if (const char* e = getenv("WT_GEMM16S_DBG")) b.dbg = atoi(e);
     if (!b.status) b.status = g_launch.status;
     hipLaunchKernelGGL(kern, dim3(G, 1, a.nz), dim3(64 * WMs * WNs), smem, s, b);
     WT_HIP_CHECK(hipGetLastError());

@@ -84,7 +84,8 @@ __device__ __forceinline__ int rb16_woff(int rows, int ks, int hl, int n, int h)
     return ((ks * 2 + hl) * rows + n) * 32 + ((h ^ ((n >> 3) & 1)) * 16);
 }
 
-template <int C, int ROWS, int FOLD>
+// DBG: timing-experiment build (WT_RB16_DBG); the shipped instantiations test nothing at run time
+template <int C, int ROWS, int FOLD, bool DBG = false>
 __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs a) {
     using L = Rb16Layout<C, ROWS>;
     using XR = RbRow<C>;
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs
 
     const int fl = lane & 31, fh = lane >> 5;        // MFMA lane: (row or column fl, k half fh)
     const int row0 = wave * 32;                      // this wave's frames inside the tile
-    const int dbg = a.dbg;                           // timing experiments only (WT_RB16_DBG): 1 no tile fill, 2 no MFMA, 4 no store
+    const int dbg = DBG ? a.dbg : 0;                 // timing experiments only (WT_RB16_DBG): 1 no tile fill, 2 no MFMA, 4 no store
     constexpr float LO_SCALE = 1.f / 2048.f;
 
     for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -385,16 +386,21 @@ static int launch_rb16(const ResblockArgs& a, hipStream_t s) {
     constexpr size_t smem = (size_t)Rb16Layout<C, ROWS>::total;
     static_assert(smem <= 160 * 1024, "LDS budget");
     auto kern = resblock16_kernel<C, ROWS, FOLD>;
+    int dbg_req = 0;
+    if (const char* e = getenv("WT_RB16_DBG")) dbg_req = atoi(e);
+    if (dbg_req) kern = resblock16_kernel<C, ROWS, FOLD, true>;
     if (int rc = attr_once.run([&]() -> int {
-        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)smem));
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock16_kernel<C, ROWS, FOLD>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock16_kernel<C, ROWS, FOLD, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         return 0;
     })) return rc;
     const long tiles = (long)a.B * ((a.T + ROWS - 1) / ROWS);
     const int per_cu = (int)(160 * 1024 / smem) < 4 ? (int)(160 * 1024 / smem) : 4;
     const long grid = tiles < 256L * per_cu ? tiles : 256L * per_cu;
     ResblockArgs b = a;
-    if (const char* e = getenv("WT_RB16_DBG")) b.dbg = atoi(e);
+    b.dbg = dbg_req;
     if (!b.status) b.status = g_launch.status;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(ROWS * 2), smem, s, b);
     WT_HIP_CHECK(hipGetLastError());
