@@ -111,6 +111,17 @@ const char* wt_version(void);
 int  wt_model_create(const wt_arch* arch, const wt_tensor* tensors, int32_t n_tensors, int32_t device,
                      wt_model** out);
 void wt_model_destroy(wt_model* m);
+
+/* Packed weight image ("a packed on-disk weight format, folded, pre-tiled, for fast start"): everything
+ * wt_model_create computes and leaves in HBM — weight-norm folded conv weights in [Cout][tap][Cin], LSTM gate-row
+ * packings, the packed ISTFT head and inverse-DFT basis, the S32 / f16x2 split copies with their per-tensor scales —
+ * behind a header (magic, layout version, the wt_arch, a hash of both).  wt_model_create_packed allocates, uploads and
+ * fixes up pointers: nothing is folded, packed or split again (replaces the load_state_dict + per-forward weight_norm of
+ * decoder/pretrained.py:95-114 a second time over).  wt_packed_info validates a header without a GPU. */
+size_t wt_model_export_bytes(const wt_model* m);
+int  wt_model_export(const wt_model* m, void* buf, size_t n);
+int  wt_packed_info(const void* buf, size_t n, wt_arch* arch, int32_t* version, uint64_t* arch_hash);
+int  wt_model_create_packed(const void* buf, size_t n, int32_t device, wt_model** out);
 int  wt_model_hop(const wt_model* m);                 /* prod(ratios) */
 int64_t wt_model_weight_bytes(const wt_model* m);     /* packed fp32 bytes resident in HBM */
 

@@ -900,3 +900,41 @@ def test_graph_replay_single_clip_alternating_plans(gpu_model):
             assert torch.equal(f, f0), (T, rep)
             assert torch.equal(y, y0), (T, rep)
     m.check_status()
+
+
+def test_packed_image_round_trip(gpu_model, tmp_path):
+    """save_packed / from_packed: the image of the model as it sits in HBM loads without recomputation into a
+    model whose own image is byte-identical (every folded / packed / split array and the pointer table) and whose outputs
+    equal the original's bit for bit; the load times of both routes are recorded."""
+    import hashlib
+    import time
+    import yaml
+    from wavtokenizer_amd import WavTokenizer, NAMED_ARCHS, synth
+    from tests import parity_log
+    name, m, sd = gpu_model
+    arch = NAMED_ARCHS[name]
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text(yaml.safe_dump({"model": {"init_args": arch.to_yaml_node()}}))
+    path = str(tmp_path / "model.wtpk")
+    m.save_packed(path)
+    t0 = time.perf_counter()
+    m2 = WavTokenizer.from_packed(str(cfg), path)
+    torch.cuda.synchronize()
+    t_packed = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    m3 = WavTokenizer.from_arch(arch)
+    m3.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    m3 = m3.eval().to("cuda")
+    m3._ensure_engine()
+    torch.cuda.synchronize()
+    t_state = time.perf_counter() - t0
+    img1, img2 = m._engine.export(), m2._engine.export()
+    assert hashlib.sha256(img1.tobytes()).hexdigest() == hashlib.sha256(img2.tobytes()).hexdigest()
+    wav = torch.from_numpy(synth.make_clips(3, 12000, seed=41)).cuda()
+    f1, c1 = m.encode_infer(wav, bandwidth_id=BW)
+    f2, c2 = m2.encode_infer(wav, bandwidth_id=BW)
+    assert torch.equal(c1, c2) and torch.equal(f1, f2)
+    assert torch.equal(m.decode(f1, bandwidth_id=BW), m2.decode(f2, bandwidth_id=BW))
+    with pytest.raises(RuntimeError):
+        m2.state_dict()
+    parity_log.record(f"packed_load[{name}]", image_mb=img1.nbytes / 1e6, from_packed_s=t_packed, from_state_dict_s=t_state)

@@ -209,11 +209,11 @@ def test_packed_weights_round_trip(tmp_path):
     sd = _fake_lightning_ckpt(str(tmp_path / "m.ckpt"), "hop600")
     m = WavTokenizer.from_pretrained0802(cfg, str(tmp_path / "m.ckpt"))
     path = str(tmp_path / "hot_path.safetensors")
-    m.save_packed(path)
+    m.save_hot_state(path)
     with safe_open(path, framework="pt") as f:
         assert set(f.keys()) == set(m.state_dict().keys()) and len(list(f.keys())) == 289
-        assert f.metadata()["format"] == "wavtokenizer_amd.packed.v1"
-    m2 = WavTokenizer.from_packed(cfg, path)
+        assert f.metadata()["format"] == "wavtokenizer_amd.hot_state.v1"
+    m2 = WavTokenizer.from_hot_state(cfg, path)
     assert not m2.training
     for k, v in m.state_dict().items():
         assert torch.equal(m2.state_dict()[k], v), k
@@ -238,3 +238,31 @@ def test_graph_plan_selection_is_host_logic():
     assert m._graph_flags(2) == (_capi.WT_PLAN_FLAG_STEP_LSTM | _capi.WT_PLAN_FLAG_GRAPH)
     assert {_capi.WT_PLAN_FLAG_KEEP_STAGES, _capi.WT_PLAN_FLAG_FP32_GEMM, _capi.WT_PLAN_FLAG_STEP_LSTM,
             _capi.WT_PLAN_FLAG_GRAPH} == {1, 2, 4, 8}
+
+
+def test_packed_image_header_is_validated_without_a_gpu():
+    """wt_packed_info (the header check of from_packed): magic, layout version, architecture hash, truncation."""
+    import ctypes
+    import numpy as np
+    from wavtokenizer_amd import _capi
+    lib = _capi.lib
+
+    def info(buf):
+        wa, ver, ah = _capi.WtArch(), ctypes.c_int32(), ctypes.c_uint64()
+        rc = lib.wt_packed_info(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes, ctypes.byref(wa), ctypes.byref(ver), ctypes.byref(ah))
+        return rc, lib.wt_last_error().decode()
+
+    rc, msg = info(np.zeros(16, np.uint8))
+    assert rc != 0 and "short" in msg
+    junk = np.frombuffer(b"NOPE" + bytes(4096), dtype=np.uint8).copy()
+    rc, msg = info(junk)
+    assert rc != 0 and "magic" in msg
+    # a header with the right magic but another layout version
+    hdr = np.zeros(4096, np.uint8)
+    hdr[:4] = np.frombuffer(b"WTPK", dtype=np.uint8)
+    hdr[4:8] = np.frombuffer(np.int32(1).tobytes(), dtype=np.uint8)
+    rc, msg = info(hdr)
+    assert rc != 0 and "version" in msg
+    hdr[4:8] = np.frombuffer(np.int32(2).tobytes(), dtype=np.uint8)
+    rc, msg = info(hdr)
+    assert rc != 0 and "hash" in msg                   # zeroed architecture + zero hash: caught as a corrupt header

@@ -15,7 +15,8 @@ LIB_PATH = os.environ.get("WAVTOK_HIP_LIB") or os.path.join(_HERE, "libwavtok_hi
 
 # every symbol include/wavtokenizer_amd.h declares
 EXPORTS = [
-    "wt_last_error", "wt_version", "wt_model_create", "wt_model_destroy", "wt_model_hop", "wt_model_weight_bytes",
+    "wt_last_error", "wt_version", "wt_model_create", "wt_model_destroy", "wt_model_export_bytes", "wt_model_export", "wt_packed_info",
+    "wt_model_create_packed", "wt_model_hop", "wt_model_weight_bytes",
     "wt_plan_create", "wt_plan_destroy", "wt_plan_workspace_bytes", "wt_plan_frames", "wt_plan_num_launches", "wt_plan_graph_replays",
     "wt_plan_find_buffer", "wt_plan_buffer_info", "wt_plan_buffer_name", "wt_plan_status", "wt_plan_num_steps", "wt_plan_step_name",
     "wt_plan_set_timing", "wt_plan_read_timing", "wt_model_split_ok", "wt_model_take_bad_codes", "wt_encode", "wt_codes_to_features",
@@ -64,6 +65,11 @@ def _load() -> ctypes.CDLL:
     lib.wt_model_create.argtypes = [POINTER(WtArch), POINTER(WtTensor), c_int32, c_int32, POINTER(c_void_p)]
     lib.wt_model_destroy.argtypes = [c_void_p]
     lib.wt_model_destroy.restype = None
+    lib.wt_model_export_bytes.argtypes = [c_void_p]
+    lib.wt_model_export_bytes.restype = c_size_t
+    lib.wt_model_export.argtypes = [c_void_p, c_void_p, c_size_t]
+    lib.wt_packed_info.argtypes = [c_void_p, c_size_t, POINTER(WtArch), POINTER(c_int32), POINTER(ctypes.c_uint64)]
+    lib.wt_model_create_packed.argtypes = [c_void_p, c_size_t, c_int32, POINTER(c_void_p)]
     lib.wt_model_hop.argtypes = [c_void_p]
     lib.wt_model_weight_bytes.argtypes = [c_void_p]
     lib.wt_model_weight_bytes.restype = c_int64

@@ -55,6 +55,22 @@ class ArchConfig:
         (encoder/modules/conv.py:54-61)."""
         return -(-T // self.hop)
 
+    def to_yaml_node(self) -> Dict[str, Any]:
+        """The `model.init_args` sub-tree of a Lightning-CLI YAML that arch_from_yaml_dict parses back into this
+        architecture (the keys decoder/pretrained.py:81-92 reads)."""
+        return {
+            "feature_extractor": {"class_path": "decoder.feature_extractors.EncodecFeatures",
+                                  "init_args": {"encodec_model": "encodec_24khz", "bandwidths": list(self.bandwidths),
+                                                "dowmsamples": list(self.ratios), "vq_bins": self.vq_bins,
+                                                "num_quantizers": self.num_quantizers}},
+            "backbone": {"class_path": "decoder.models.VocosBackbone",
+                         "init_args": {"input_channels": self.input_channels, "dim": self.dim,
+                                       "intermediate_dim": self.intermediate_dim, "num_layers": self.num_layers,
+                                       "adanorm_num_embeddings": self.adanorm_num_embeddings}},
+            "head": {"class_path": "decoder.heads.ISTFTHead",
+                     "init_args": {"dim": self.dim, "n_fft": self.n_fft, "hop_length": self.hop_length, "padding": self.padding}},
+        }
+
     def to_dict(self) -> Dict[str, Any]:
         d = dataclasses.asdict(self)
         d["ratios"] = list(self.ratios)

@@ -57,6 +57,45 @@ int wt_model_create(const wt_arch* arch, const wt_tensor* tensors, int32_t n_ten
     return WT_OK;
 }
 
+size_t wt_model_export_bytes(const wt_model* m) { return m ? model_export_bytes(m) : 0; }
+int wt_model_export(const wt_model* m, void* buf, size_t n) {
+    if (!m || !buf) { set_error("wt_model_export: null argument"); return WT_ERR_INVALID; }
+    DeviceGuard dg(m->device);
+    if (!dg.ok) { set_error("hipSetDevice failed"); return WT_ERR_HIP; }
+    return model_export(m, buf, n);
+}
+int wt_packed_info(const void* buf, size_t n, wt_arch* arch, int32_t* version, uint64_t* arch_hash) {
+    return packed_info(buf, n, arch, version, arch_hash);
+}
+int wt_model_create_packed(const void* buf, size_t n, int32_t device, wt_model** out) {
+    if (!buf || !out) { set_error("wt_model_create_packed: null argument"); return WT_ERR_INVALID; }
+    if (int rc = packed_info(buf, n, nullptr, nullptr, nullptr)) return rc;
+    DeviceGuard dg(device);
+    if (!dg.ok) { set_error("wt_model_create_packed: hipSetDevice failed"); return WT_ERR_HIP; }
+    std::unique_ptr<wt_model> M(new wt_model());
+    M->device = device;
+    int rc = model_import(M.get(), buf, n);
+    if (!rc) {
+        void* hp = nullptr;
+        void* dp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+            if (hp) (void)hipHostFree(hp);
+            set_error("wt_model_create_packed: no host-mapped memory for the status word");
+            rc = WT_ERR_HIP;
+        } else {
+            M->bad_codes_host = static_cast<unsigned*>(hp);
+            M->bad_codes_dev = static_cast<unsigned*>(dp);
+            *M->bad_codes_host = 0;
+        }
+    }
+    if (rc) {
+        for (void* p : M->allocs) (void)hipFree(p);
+        return rc;
+    }
+    *out = M.release();
+    return WT_OK;
+}
+
 void wt_model_destroy(wt_model* m) {
     if (!m) return;
     DeviceGuard dg(m->device);

@@ -61,6 +61,7 @@ struct wt_model {
     int H = 512;
     std::vector<int> enc_ratios;
     std::vector<void*> allocs;
+    std::vector<size_t> alloc_bytes;     // size of each allocation (the packed image stores them in this order)
     int64_t weight_bytes = 0;
     // f16 (hi, lo) copies of the weight matrices the split-precision GEMM (gemm16.hip) reads, keyed by the
     // fp32 device pointer the plans already use; `lo_off` = elements between the hi and the lo array
@@ -252,6 +253,11 @@ namespace wt {
 // weights.cpp
 int build_model(wt_model* M, TensorMap& tm);
 int build_splits(wt_model* M);
+// packed image of a model (weights.cpp): everything wt_model_create computes and uploads, ready to upload again
+size_t model_export_bytes(const wt_model* M);
+int model_export(const wt_model* M, void* buf, size_t n);
+int model_import(wt_model* M, const void* buf, size_t n);        // M->device set; allocates and uploads
+int packed_info(const void* buf, size_t n, wt_arch* arch, int32_t* version, uint64_t* arch_hash);
 // plan.cpp
 struct SConvGeom { int pl, pr_total, Tout, Tp; };
 SConvGeom sconv_geom(long T, int k, int stride, int dil);

@@ -10,6 +10,7 @@ static int upload(wt_model* M, const std::vector<float>& h, float** out) {
     size_t bytes = std::max<size_t>(h.size(), 4) * sizeof(float);
     WT_HIP_CHECK(hipMalloc(&d, bytes));
     M->allocs.push_back(d);
+    M->alloc_bytes.push_back(bytes);
     WT_HIP_CHECK(hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
     M->weight_bytes += (int64_t)h.size() * sizeof(float);
     *out = static_cast<float*>(d);
@@ -393,6 +394,7 @@ static int add_split(wt_model* M, const float* w, long n) {
     void* d = nullptr;
     WT_HIP_CHECK(hipMalloc(&d, (size_t)n * 4));
     M->allocs.push_back(d);
+    M->alloc_bytes.push_back((size_t)n * 4);
     M->weight_bytes += n * 4;
     if (int rc = launch_split_f16x2(w, d, static_cast<char*>(d) + (size_t)n * 2, n, nullptr)) return rc;
     M->split16[w] = {d, n};
@@ -432,6 +434,7 @@ static int add_s32(wt_model* M, const float* w, long n, bool* split_ok = nullptr
     void* d = nullptr;
     WT_HIP_CHECK(hipMalloc(&d, (size_t)n * 4));
     M->allocs.push_back(d);
+    M->alloc_bytes.push_back((size_t)n * 4);
     M->weight_bytes += n * 4;
     if (int rc = launch_split_s32(w, d, n, nullptr, scale_dev)) return rc;
     M->s32[w] = d;
@@ -533,6 +536,191 @@ int build_splits(wt_model* M) {
     }
     WT_HIP_CHECK(hipDeviceSynchronize());
     return 0;
+}
+
+
+// ------------------------------------------------------------------------------------ packed image
+// a packed on-disk weight format "folded, pre-tiled".  The image is what wt_model_create leaves in HBM —
+// folded conv weights in [Cout][tap][Cin], LSTM gate-row packings, the packed head and inverse-DFT basis, the S32 and
+// f16x2 split copies with their per-tensor scales — as the list of device allocations in creation order, preceded by a
+// header (magic, version, the wt_arch and a hash of it) and the model struct with every pointer written as
+// (allocation index).  Loading it is allocate + upload + fix up pointers: nothing is folded, packed or split again.
+static constexpr uint32_t PACK_MAGIC = 0x4b505457u;     // "WTPK"
+static constexpr int32_t PACK_VERSION = 2;
+
+static uint64_t arch_hash_of(const wt_arch& a) {        // FNV-1a over the architecture struct and the layout version
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t n) { for (size_t i = 0; i < n; ++i) { h ^= static_cast<const unsigned char*>(p)[i]; h *= 1099511628211ull; } };
+    mix(&a, sizeof(a));
+    mix(&PACK_VERSION, sizeof(PACK_VERSION));
+    return h;
+}
+
+struct Archive {
+    bool saving;
+    std::vector<char>* out = nullptr;          // saving
+    const char* in = nullptr;                  // loading
+    size_t pos = 0, n = 0;
+    bool ok = true;
+    const std::map<const void*, int>* index = nullptr;      // saving: allocation base -> index
+    const std::vector<void*>* allocs = nullptr;             // loading: index -> allocation base
+    void raw(void* p, size_t bytes) {
+        if (saving) { const char* c = static_cast<const char*>(p); out->insert(out->end(), c, c + bytes); }
+        else { if (pos + bytes > n) { ok = false; return; } std::memcpy(p, in + pos, bytes); pos += bytes; }
+    }
+    template <class T> void pod(T& v) { raw(&v, sizeof(T)); }
+    template <class T> void ptr(T*& p) {       // a device pointer = (allocation index, byte offset); -1 = null
+        int32_t idx = -1;
+        int64_t off = 0;
+        if (saving && p) {
+            auto it = index->upper_bound(static_cast<const void*>(p));
+            if (it == index->begin()) { ok = false; }
+            else { --it; idx = it->second; off = reinterpret_cast<const char*>(p) - static_cast<const char*>(it->first); }
+        }
+        pod(idx); pod(off);
+        if (!saving) {
+            if (idx < 0) p = nullptr;
+            else if (idx >= (int)allocs->size()) { ok = false; p = nullptr; }
+            else p = reinterpret_cast<T*>(static_cast<char*>((*allocs)[idx]) + off);
+        }
+    }
+    void conv(ConvW& c) { ptr(c.w); ptr(c.b); pod(c.cout); pod(c.cin); pod(c.k); }
+    void lstm(LstmW& l) { ptr(l.Wih0); ptr(l.b0); ptr(l.W0); ptr(l.W1); ptr(l.b1); ptr(l.W0h); ptr(l.W1h); ptr(l.Wp); }
+};
+
+static void archive_model(Archive& ar, wt_model* M) {
+    ar.pod(M->hop); ar.pod(M->H); ar.pod(M->weight_bytes); ar.pod(M->s32_ok); ar.pod(M->sd_s32_ok); ar.pod(M->w_amax);
+    int32_t n = (int32_t)M->enc_ratios.size();
+    ar.pod(n);
+    M->enc_ratios.resize(n);
+    for (int& r : M->enc_ratios) ar.pod(r);
+    ar.ptr(M->e0_w); ar.ptr(M->e0_b); ar.pod(M->e0_k); ar.pod(M->e0_c);
+    n = (int32_t)M->stages.size(); ar.pod(n); M->stages.resize(n);
+    for (ResStage& st : M->stages) { ar.conv(st.c3); ar.conv(st.c1); ar.conv(st.sc); ar.conv(st.down); ar.pod(st.C); ar.pod(st.r); }
+    ar.lstm(M->enc_lstm); ar.conv(M->enc_final); ar.ptr(M->embed); ar.ptr(M->ee);
+    ar.conv(M->bb_embed);
+    for (PosRes& r : M->res) { ar.ptr(r.n1w); ar.ptr(r.n1b); ar.ptr(r.n2w); ar.ptr(r.n2b); ar.conv(r.c1); ar.conv(r.c2); }
+    ar.ptr(M->at_nw); ar.ptr(M->at_nb); ar.ptr(M->at_Wqk); ar.ptr(M->at_bqk); ar.ptr(M->at_Wv); ar.ptr(M->at_bv); ar.ptr(M->at_Wp); ar.ptr(M->at_bp);
+    ar.ptr(M->gn5w); ar.ptr(M->gn5b); ar.ptr(M->ada_s); ar.ptr(M->ada_h);
+    n = (int32_t)M->cnx.size(); ar.pod(n); M->cnx.resize(n);
+    for (CnxBlock& c : M->cnx) { ar.ptr(c.dw_w); ar.ptr(c.dw_b); ar.ptr(c.ada_s); ar.ptr(c.ada_h); ar.ptr(c.W1); ar.ptr(c.b1); ar.ptr(c.W2); ar.ptr(c.b2); ar.ptr(c.gamma); }
+    ar.ptr(M->fln_w); ar.ptr(M->fln_b); ar.ptr(M->head_W); ar.ptr(M->head_b);
+    ar.pod(M->Kb); ar.pod(M->Kq); ar.pod(M->bins_f); ar.pod(M->R);
+    ar.ptr(M->istft_W); ar.ptr(M->wsq); ar.ptr(M->win);
+    ar.pod(M->has_seadec); ar.conv(M->sd_first); ar.lstm(M->sd_lstm);
+    n = (int32_t)M->sd_stages.size(); ar.pod(n); M->sd_stages.resize(n);
+    for (SeaDecStage& st : M->sd_stages) {
+        ar.ptr(st.tr_w); ar.ptr(st.tr_wp); ar.ptr(st.tr_b); ar.pod(st.cin); ar.pod(st.cout); ar.pod(st.k); ar.pod(st.r);
+        ar.conv(st.c3); ar.conv(st.c1); ar.conv(st.sc);
+    }
+    ar.ptr(M->sd_last_w); ar.ptr(M->sd_last_b);
+    // the maps keyed by the fp32 weight pointer
+    auto map_ptr = [&](auto& m, auto value_io) {
+        int32_t cnt = (int32_t)m.size();
+        ar.pod(cnt);
+        if (ar.saving) {
+            // in allocation order, not in address order: the image of a model does not depend on where hipMalloc put it
+            std::vector<const float*> keys;
+            for (auto& kv : m) keys.push_back(kv.first);
+            auto alloc_of = [&](const float* k) { auto it = ar.index->upper_bound(static_cast<const void*>(k)); return it == ar.index->begin() ? -1 : std::prev(it)->second; };
+            std::sort(keys.begin(), keys.end(), [&](const float* a, const float* b) { return alloc_of(a) < alloc_of(b); });
+            for (const float* k0 : keys) { const float* k = k0; ar.ptr(k); value_io(m.at(k0)); }
+        } else {
+            for (int i = 0; i < cnt && ar.ok; ++i) { const float* k = nullptr; ar.ptr(k); auto& v = m[k]; value_io(v); }
+        }
+    };
+    map_ptr(M->split16, [&](wt_model::Split16& v) { ar.ptr(v.hi); ar.pod(v.lo_off); });
+    map_ptr(M->s32, [&](void*& v) { ar.ptr(v); });
+    map_ptr(M->s32_tap_pair, [&](bool& v) { ar.pod(v); });
+    map_ptr(M->s32_acc_scale, [&](float& v) { ar.pod(v); });
+}
+
+struct PackHeader {
+    uint32_t magic;
+    int32_t version;
+    wt_arch arch;
+    uint64_t arch_hash;
+    uint64_t n_allocs, struct_bytes, payload_bytes;
+};
+
+size_t model_export_bytes(const wt_model* M) {
+    size_t total = sizeof(PackHeader) + M->allocs.size() * sizeof(uint64_t) + (1u << 16);      // struct section: generous bound
+    for (size_t b : M->alloc_bytes) total += (b + 255) / 256 * 256;
+    return total + 256;
+}
+
+int model_export(const wt_model* Mc, void* buf, size_t n) {
+    wt_model* M = const_cast<wt_model*>(Mc);         // archive_model is symmetric; saving does not modify
+    std::map<const void*, int> index;
+    for (size_t i = 0; i < M->allocs.size(); ++i) index[M->allocs[i]] = (int)i;
+    std::vector<char> st;
+    Archive ar;
+    ar.saving = true; ar.out = &st; ar.index = &index;
+    archive_model(ar, M);
+    if (!ar.ok) { set_error("wt_model_export: a model pointer lies outside the model's allocations"); return WT_ERR_INVALID; }
+    PackHeader h{};
+    h.magic = PACK_MAGIC; h.version = PACK_VERSION; h.arch = M->arch; h.arch_hash = arch_hash_of(M->arch);
+    h.n_allocs = M->allocs.size(); h.struct_bytes = st.size();
+    size_t pos = sizeof(PackHeader) + M->allocs.size() * sizeof(uint64_t) + st.size();
+    pos = (pos + 255) / 256 * 256;
+    const size_t payload0 = pos;
+    for (size_t b : M->alloc_bytes) pos += (b + 255) / 256 * 256;
+    h.payload_bytes = pos - payload0;
+    if (pos > n) { set_error("wt_model_export: buffer too small (wt_model_export_bytes)"); return WT_ERR_INVALID; }
+    char* o = static_cast<char*>(buf);
+    std::memset(o, 0, payload0);
+    std::memcpy(o, &h, sizeof(h));
+    for (size_t i = 0; i < M->allocs.size(); ++i) { uint64_t b = M->alloc_bytes[i]; std::memcpy(o + sizeof(h) + i * 8, &b, 8); }
+    std::memcpy(o + sizeof(h) + M->allocs.size() * 8, st.data(), st.size());
+    pos = payload0;
+    WT_HIP_CHECK(hipDeviceSynchronize());
+    for (size_t i = 0; i < M->allocs.size(); ++i) {
+        const size_t b = M->alloc_bytes[i], padded = (b + 255) / 256 * 256;
+        WT_HIP_CHECK(hipMemcpy(o + pos, M->allocs[i], b, hipMemcpyDeviceToHost));
+        std::memset(o + pos + b, 0, padded - b);
+        pos += padded;
+    }
+    return (int)0;
+}
+
+int packed_info(const void* buf, size_t n, wt_arch* arch, int32_t* version, uint64_t* arch_hash) {
+    if (!buf || n < sizeof(PackHeader)) { set_error("packed image: too short"); return WT_ERR_INVALID; }
+    PackHeader h;
+    std::memcpy(&h, buf, sizeof(h));
+    if (h.magic != PACK_MAGIC) { set_error("packed image: bad magic (not a wavtokenizer_amd packed file)"); return WT_ERR_INVALID; }
+    if (version) *version = h.version;
+    if (arch) *arch = h.arch;
+    if (arch_hash) *arch_hash = h.arch_hash;
+    if (h.version != PACK_VERSION) { set_error("packed image: layout version " + std::to_string(h.version) + ", this library reads " + std::to_string(PACK_VERSION)); return WT_ERR_INVALID; }
+    if (h.arch_hash != arch_hash_of(h.arch)) { set_error("packed image: architecture hash mismatch (corrupt header)"); return WT_ERR_INVALID; }
+    const size_t head = sizeof(PackHeader) + h.n_allocs * 8 + h.struct_bytes;
+    if (h.n_allocs > (1u << 20) || head > n || (head + 255) / 256 * 256 + h.payload_bytes > n) { set_error("packed image: truncated"); return WT_ERR_INVALID; }
+    return WT_OK;
+}
+
+int model_import(wt_model* M, const void* buf, size_t n) {
+    PackHeader h;
+    if (int rc = packed_info(buf, n, &M->arch, nullptr, nullptr)) return rc;
+    std::memcpy(&h, buf, sizeof(h));
+    const char* in = static_cast<const char*>(buf);
+    size_t pos = (sizeof(PackHeader) + h.n_allocs * 8 + h.struct_bytes + 255) / 256 * 256;
+    for (size_t i = 0; i < h.n_allocs; ++i) {
+        uint64_t b;
+        std::memcpy(&b, in + sizeof(h) + i * 8, 8);
+        const size_t padded = (b + 255) / 256 * 256;
+        if (pos + padded > n) { set_error("packed image: truncated payload"); return WT_ERR_INVALID; }
+        void* d = nullptr;
+        WT_HIP_CHECK(hipMalloc(&d, b));
+        M->allocs.push_back(d);
+        M->alloc_bytes.push_back(b);
+        WT_HIP_CHECK(hipMemcpy(d, in + pos, b, hipMemcpyHostToDevice));
+        pos += padded;
+    }
+    Archive ar;
+    ar.saving = false; ar.in = in + sizeof(h) + h.n_allocs * 8; ar.n = h.struct_bytes; ar.allocs = &M->allocs;
+    archive_model(ar, M);
+    if (!ar.ok || ar.pos != ar.n) { set_error("packed image: model section does not match this library's layout"); return WT_ERR_INVALID; }
+    return WT_OK;
 }
 
 }  // namespace wt

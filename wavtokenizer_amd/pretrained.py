@@ -199,6 +199,19 @@ class _Engine:
               "wt_model_create")
         self.device_index = device_index
 
+    def load_packed(self, image: np.ndarray, device_index: int):
+        """Upload a packed image (WavTokenizer.save_packed): nothing is folded, packed or split again."""
+        self.close()
+        check(lib.wt_model_create_packed(image.ctypes.data_as(ctypes.c_void_p), image.nbytes, device_index,
+                                         ctypes.byref(self.model)), "wt_model_create_packed")
+        self.device_index = device_index
+
+    def export(self) -> np.ndarray:
+        n = lib.wt_model_export_bytes(self.model)
+        buf = np.empty(n, dtype=np.uint8)
+        check(lib.wt_model_export(self.model, buf.ctypes.data_as(ctypes.c_void_p), n), "wt_model_export")
+        return buf
+
     def plan(self, kind: int, B: int, length: int, flags: int, device: torch.device):
         key = (kind, B, length, flags)
         hit = self.plans.pop(key, None)
@@ -328,23 +341,63 @@ class WavTokenizer(nn.Module):
         model.eval()
         return model
 
-    # -- packed weights: one pickle-free file holding exactly the hot-path tensors ---------------------------------
-    def save_packed(self, path: str) -> None:
+    # -- hot-path state: one pickle-free file holding exactly the hot-path tensors ------------------------------------
+    def save_hot_state(self, path: str) -> None:
         """Write the hot-path state (the 289 reference keys this class keeps; discriminators, optimizer state and
         the rest of a Lightning checkpoint are gone) as one safetensors file: nothing is executed when it is read
         back, and it loads without unpickling a multi-GB training checkpoint."""
         from safetensors.torch import save_file
         sd = {k: v.detach().to("cpu", copy=True).contiguous() for k, v in self.state_dict().items()}
-        save_file(sd, path, metadata={"format": "wavtokenizer_amd.packed.v1", "hop": str(self._arch.hop)})
+        save_file(sd, path, metadata={"format": "wavtokenizer_amd.hot_state.v1", "hop": str(self._arch.hop)})
 
     @classmethod
-    def from_packed(cls, config_path: str, packed_path: str) -> "WavTokenizer":
-        """Counterpart of from_pretrained0802 (pretrained.py:95-114) for a file written by save_packed."""
+    def from_hot_state(cls, config_path: str, path: str) -> "WavTokenizer":
+        """Counterpart of from_pretrained0802 (pretrained.py:95-114) for a file written by save_hot_state."""
         from safetensors.torch import load_file
         model = cls.from_hparams0802(config_path)
-        model.load_state_dict(load_file(packed_path, device="cpu"))
+        model.load_state_dict(load_file(path, device="cpu"))
         model.eval()
         return model
+
+    # -- packed image: what sits in HBM after loading, ready to upload again (SURVEY 8(f)3) ------------------------------
+    def save_packed(self, path: str) -> None:
+        """Write the model as it sits in HBM (folded conv weights in [Cout][tap][Cin], LSTM lane packings, the packed
+        ISTFT head and inverse-DFT basis, the S32 / f16x2 split copies and their scales) behind a header with a layout
+        version and an architecture hash.  from_packed uploads it without folding, packing or splitting anything again.
+        The model must be on the GPU (the image is read back from there)."""
+        self._ensure_engine()
+        self._engine.export().tofile(path)
+
+    @classmethod
+    def from_packed(cls, config_path: str, packed_path: str, device="cuda") -> "WavTokenizer":
+        """Counterpart of from_pretrained0802 (pretrained.py:95-114) for a file written by save_packed: the file is
+        memory-mapped and uploaded as it is.  The returned model keeps no copy of the reference's raw tensors (its
+        nn.Module parameters are placeholders): state_dict() raises, load_state_dict() turns it into a normal model."""
+        model = cls.from_hparams0802(config_path)
+        image = np.memmap(packed_path, dtype=np.uint8, mode="r")
+        wa, ver, ah = WtArch(), ctypes.c_int32(), ctypes.c_uint64()
+        check(lib.wt_packed_info(image.ctypes.data_as(ctypes.c_void_p), image.nbytes, ctypes.byref(wa), ctypes.byref(ver),
+                                 ctypes.byref(ah)), "wt_packed_info")
+        a = model._arch
+        mine = (len(a.ratios), tuple(a.ratios), a.vq_bins, a.dim, a.intermediate_dim, a.num_layers, a.n_fft, a.hop_length)
+        theirs = (wa.n_ratios, tuple(wa.ratios[i] for i in range(wa.n_ratios)), wa.vq_bins, wa.dim, wa.intermediate_dim,
+                  wa.num_layers, wa.n_fft, wa.hop_length)
+        if mine != theirs:
+            raise ValueError(f"packed file was written for another architecture: {theirs} (config says {mine})")
+        dev = torch.device(device)
+        model.eval()
+        model = model.to(dev)
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        model._engine.load_packed(np.asarray(image), idx)
+        model._dirty = False
+        model._packed_only = True
+        return model
+
+    def state_dict(self, *a, **kw):
+        if getattr(self, "_packed_only", False):
+            raise RuntimeError("this model was loaded from a packed image (from_packed): it holds the folded and packed "
+                               "weights in HBM, not the reference's raw tensors; load a checkpoint to get a state_dict")
+        return super().state_dict(*a, **kw)
 
     @classmethod
     def from_pretrained(cls, repo_id: str) -> "WavTokenizer":
@@ -361,11 +414,13 @@ class WavTokenizer(nn.Module):
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         out = super().load_state_dict(state_dict, strict=strict, **kw)
         self._dirty = True
+        self._packed_only = False
         return out
 
     def _apply(self, fn, *a, **kw):
         out = super()._apply(fn, *a, **kw)
-        self._dirty = True
+        if not getattr(self, "_packed_only", False):      # a packed model has nothing to re-pack from
+            self._dirty = True
         return out
 
     def refresh_weights(self):
