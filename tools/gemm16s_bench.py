@@ -107,7 +107,7 @@ def main():
         for mode, mn in ((2, "bias -> fp32"),):
             linear(f"pwconv1 {mn} shipped build", 7680, 2304, 768, mode, 2)
             for dbg, dn in ((1024, "full (stamped)"), (4, "no epilogue"), (5, "no epilogue, no DMA"), (13, "no epilogue, no DMA, no barrier"),
-                            (45, "MFMA + LDS fragment reads"), (61, "MFMA only"), (2048, "full, every wave issues its DMA at the top of the step"), (64, "full, younger half at priority 1")):
+                            (45, "MFMA + LDS fragment reads"), (61, "MFMA only"), (21, "no epilogue, no DMA, no LDS reads"), (64, "full, younger half at priority 1")):
                 os.environ["WT_GEMM16S_DBG"] = str(dbg)
                 linear(f"pwconv1 {mn}: {dn}", 7680, 2304, 768, mode, 2)
                 os.environ.pop("WT_GEMM16S_DBG")

@@ -114,7 +114,7 @@ __device__ __forceinline__ void wait_vm_lgkm() {
 
 // DBG: timing-experiment builds (WT_GEMM16S_DBG, tools/gemm16s_bench.py): a compile-time mask of phases to leave out
 // (1 DMA, 2 MFMA, 4 epilogue, 8 barrier, 16 LDS fragment reads, 32 waits, 64 static priority for the younger half, 128
-// stores, 256 bias, 512 GELU, 2048 every wave issues its DMA pieces at the top of the step; 1024: stamp s_memtime / s_memrealtime around the tile loop into GemmArgs::dbg_stamps: the
+// stores, 256 bias, 512 GELU; 1024: stamp s_memtime / s_memrealtime around the tile loop into GemmArgs::dbg_stamps: the
 // clock the chip holds).  The shipped instantiations have DBG = 0.  The mask is a template argument because a run-time
 // test in front of every phase (round 1) cuts the K loop and the epilogue into dozens of basic blocks, across which
 // hipcc neither overlaps LDS reads with MFMAs nor one 4-column run's GELU with the next one's: 108.7 -> 102.7 us on pwconv1.
@@ -391,7 +391,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
     for (int s = 0; s < NSTAGE - 1; ++s) load_tile(s);       // needs nk >= NSTAGE - 1 when a next tile exists (host)
     wait_vm_lgkm<(NSTAGE - 2) * NPT>();
     __builtin_amdgcn_s_barrier();
-    const bool dma_first = (dbg & 2048) || __builtin_amdgcn_readfirstlane(wave) < NW / 2;
     Frags F0, F1;
     FragA Fa;
     FragB F0b, F1b;
@@ -429,11 +428,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
                     for (int r = 0; r < 16; ++r) { accm[MF ? 0 : i][MF ? 0 : j][r] = 0.f; accc[MF ? 0 : i][MF ? 0 : j][r] = 0.f; }
         }
         for (int kt = 0; kt < nk; ++kt) {
-            // The two waves of a SIMD (w and w + NW/2) run the same program between the same barriers; issuing a DMA piece
-            // holds a wave's instruction issue for tens of cycles, so the older half issues its pieces before the first-half
-            // MFMAs and the younger half after them: one wave's DMA issue then runs beside its partner's MFMAs (same
-            // wait count: the pieces are the wave's youngest either way)
-            if (!(dbg & 1) && dma_first) load_tile(ws);
+            // (tried: the younger half of the waves issuing its DMA pieces after the first-half MFMAs instead of before them,
+            // so that one wave's DMA issue runs beside its SIMD partner's MFMAs: 5.79 vs 5.80 ms per step A/B on one box: nothing)
+            if (!(dbg & 1)) load_tile(ws);
             if (MF) {
                 if (!(dbg & 16)) read_b16(rs, 1, F1b);
                 if (!(dbg & 2)) mfma16_block(Fa, F0b, std::integral_constant<int, 0>{});
@@ -441,7 +438,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
                 if (!(dbg & 16)) read_frags(rs, 1, F1);
                 if (!(dbg & 2)) mfma_block(F0);
             }
-            if (!(dbg & 1) && !dma_first) load_tile(ws);
             if (!(dbg & 32)) wait_vm_lgkm<(NSTAGE - 2) * NPT>();
             if (!(dbg & 8)) __builtin_amdgcn_s_barrier();
             rs = rs + 1 == NSTAGE ? 0 : rs + 1;
@@ -777,7 +773,7 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
     int dbg_req = 0;
     if (const char* e = getenv("WT_GEMM16S_DBG")) dbg_req = atoi(e);
     kern_t dbg_kerns[8] = {};
-    static constexpr int dbg_masks[8] = {1024, 1024 + 4, 1024 + 5, 1024 + 13, 1024 + 45, 1024 + 61, 1024 + 64, 1024 + 2048};
+    static constexpr int dbg_masks[8] = {1024, 1024 + 4, 1024 + 5, 1024 + 13, 1024 + 45, 1024 + 61, 1024 + 64, 1024 + 21};
     if constexpr (has_dbg) {
         dbg_kerns[0] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024>;
         dbg_kerns[1] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024 + 4>;
@@ -786,7 +782,7 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
         dbg_kerns[4] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024 + 45>;
         dbg_kerns[5] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024 + 61>;
         dbg_kerns[6] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024 + 64>;
-        dbg_kerns[7] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024 + 2048>;
+        dbg_kerns[7] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024 + 21>;
         if (dbg_req) {
             kern = nullptr;
             for (int i = 0; i < 8; ++i) if (dbg_masks[i] == (dbg_req | 1024)) kern = dbg_kerns[i];

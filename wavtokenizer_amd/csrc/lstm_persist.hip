@@ -58,10 +58,11 @@ __device__ __forceinline__ _Float16 no_mark(_Float16 v) {
 // that is ONE L2 round trip on each side (store; load) instead of store -> acknowledge -> counter atomic -> poll -> load.
 // !DF: the arrival-counter form (two buffers), kept for comparison (WT_LSTM_PERSIST=2).
 // phase timestamps of workgroup 0 of XCD 0, steps 64..71 (WT_LSTM_TRACE=1, tools/lstm_trace.py): 100 MHz ticks into ctl[520..]
-#define LP_TRACE(ph) do { if (tr_on && s >= 64 && s < 72) { \
+#define LP_TRACE(ph) do { if (TRACE && tr_on && s >= 64 && s < 72) { \
     const unsigned long long tt = __builtin_amdgcn_s_memrealtime(); \
     if (lane == 0) { a.ctl[520 + ((s - 64) * 6 + (ph)) * 2] = (unsigned)tt; a.ctl[521 + ((s - 64) * 6 + (ph)) * 2] = (unsigned)(tt >> 32); } } } while (0)
-template <bool DF, bool SMALL>
+// TRACE: the phase-timestamp build (WT_LSTM_TRACE=1); the shipped instantiations carry no run-time test for it
+template <bool DF, bool SMALL, bool TRACE = false>
 __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersistArgs a) {
     constexpr int NBUF = DF ? 3 : 2;
     constexpr int NLDS = LpCfg<SMALL>::NLDS, HROWS = LpCfg<SMALL>::HROWS;
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
     // the spin bounds; a test hook (LstmPersistArgs::dbg_spin_shift) shortens them so that a forced loss of co-residency
     // is reported within milliseconds
     const long spin_limit = SPIN_LIMIT >> a.dbg_spin_shift, spin_limit_df = SPIN_LIMIT_DF >> a.dbg_spin_shift;
-    const bool tr_on = (a.data_flag & 4) && xcc == 0 && w == 0 && __builtin_amdgcn_readfirstlane(wave) == 0;
+    const bool tr_on = TRACE && xcc == 0 && w == 0 && __builtin_amdgcn_readfirstlane(wave) == 0;
     for (int s = 0; s <= L; ++s) {
         LP_TRACE(0);
         // layer-0 input projection of this step (independent of the recurrence): requested before the wait
@@ -352,6 +353,8 @@ int launch_lstm_persist(const LstmPersistArgs& a, hipStream_t stream) {
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_big));
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_small));
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_small));
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_big));
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_small));
         return 0;
     })) return rc;
     // the caller has filled hx and ctl with 0xFF bytes (data-flag form) or zeros (counter form)
@@ -365,7 +368,10 @@ int launch_lstm_persist(const LstmPersistArgs& a, hipStream_t stream) {
     const bool forced = fault && fault[0] == '1';
     if (forced) b.dbg_spin_shift = 8;
     const dim3 grid(forced ? 248 : 256), block(64 * PW);
-    if (a.data_flag) {
+    if (a.data_flag & 4) {          // phase timestamps (tools/lstm_trace.py)
+        if (small) hipLaunchKernelGGL((lstm_persist_kernel<true, true, true>), grid, block, smem_small, stream, b);
+        else hipLaunchKernelGGL((lstm_persist_kernel<true, false, true>), grid, block, smem_big, stream, b);
+    } else if (a.data_flag) {
         if (small) hipLaunchKernelGGL((lstm_persist_kernel<true, true>), grid, block, smem_small, stream, b);
         else hipLaunchKernelGGL((lstm_persist_kernel<true, false>), grid, block, smem_big, stream, b);
     } else {
