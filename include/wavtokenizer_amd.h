@@ -236,6 +236,11 @@ int wt_vq_nearest_f32(const float* x, const float* embed, int64_t N, int32_t D, 
 int wt_resblock(const float* x, const float* wav, const float* e0_w, const float* e0_b, const float* w3, const float* b3,
                 const float* w1, const float* b1, const float* ws, const float* bs, float* y, int32_t B, int64_t T,
                 int32_t C, int32_t elu_out, int32_t out_s32, int32_t fp32_chain, void* stream);
+/* wt_resblock's shipped stage-1 form: first conv + resblock + ELU + the stage's strided conv (seanet.py:123-127) in one
+ * launch.  wd [64][2r][32] (out, tap, in), y_down [B][T / r][64] fp32; r in {2, 4}, T % r == 0, T >= 1024. */
+int wt_resblock_down(const float* wav, const float* e0_w, const float* e0_b, const float* w3, const float* b3, const float* w1,
+                     const float* b1, const float* ws, const float* bs, const float* wd, const float* bd, float* y_down,
+                     int32_t B, int64_t T, int32_t r, void* stream);
 
 /* Runs a WT_PLAN_UNIT_LSTM plan: x, y [B][L][512] fp32 time-major; y = SLSTM(x) (encoder/modules/lstm.py:31-39) with
  * the encoder's LSTM weights of the plan's model. */

@@ -59,10 +59,11 @@ def _plan_step_names(plan):
     return names
 
 
-# taps of the reference that never exist in HBM on the shipped path: the first conv is folded into the fused stage-1
-# resblock (its effect is checked through enc.1), pos_net.5 + AdaLayerNorm are one row pass (checked through bb.norm),
-# the head's Linear output becomes the spectrum in the GEMM epilogue (checked through the waveform)
-FUSED_AWAY = {"enc.0", "bb.pos_net.5", "head.out"}
+# taps of the reference that never exist in HBM on the shipped path: the first conv and the stage-1 resblock run inside
+# the kernel that also computes the stage's down conv (checked through enc.3, and alone against the oracle in
+# test_resblock16_down_kernel_against_oracle), pos_net.5 + AdaLayerNorm are one row pass (checked through bb.norm), the
+# head's Linear output becomes the spectrum in the GEMM epilogue (checked through the waveform)
+FUSED_AWAY = {"enc.0", "enc.1", "bb.pos_net.5", "head.out"}
 
 
 @pytest.mark.parametrize("variant", ["shipped", "unfused"])
@@ -721,6 +722,45 @@ def test_resblock16_kernel_against_oracle(stage, fold, T):
         worst = max(worst, err)
         assert err < 1e-5, (stage, fold, T, elu_out, out_s32, err)
     parity_log.record(f"resblock16[stage{stage},fold={int(fold)},T={T}]", rel_l2=worst)
+
+
+@pytest.mark.parametrize("arch,T", [("hop600", 1024), ("hop600", 1116), ("hop600", 1120), ("hop600", 72000),
+                                    ("hop320", 1024), ("hop320", 1134), ("hop320", 1136), ("hop320", 72000)])
+def test_resblock16_down_kernel_against_oracle(arch, T):
+    """The shipped stage-1 kernel (first conv + SEANetResnetBlock + ELU + the stage's strided conv in one launch,
+    resblock16_kernel<DOWN = r>) against the oracle's three modules (seanet.py:117-127) on lengths around its 31- / 63-frame
+    output tiles: an exact number of tiles, one frame more, a ragged tail, the benchmark length; r = 4 (hop600) and r = 2
+    (hop320).  The first and last output frames take their reflected taps from inside the tile."""
+    import torch.nn.functional as F
+    from wavtokenizer_amd._capi import lib, check
+    from tests import parity_log
+    sd = synth_state_dict(arch)
+    orc = _oracle(arch, sd)
+    r = 4 if arch == "hop600" else 2
+    B = 3 if T < 10000 else 2
+    gen = torch.Generator().manual_seed(7 * T + r)
+    wav = torch.randn(B, T, generator=gen) * 0.3
+    w3, b3 = _fold(sd, ENC + "1.block.1.conv.conv")
+    w1, b1 = _fold(sd, ENC + "1.block.3.conv.conv")
+    ws, bs = _fold(sd, ENC + "1.shortcut.conv.conv")
+    wdn, bdn = _fold(sd, ENC + "3.conv.conv")                       # [64][2r][32]
+    e0w, e0b = _fold(sd, ENC + "0.conv.conv")
+    e0w = e0w[:, :, 0].t().contiguous()
+    assert tuple(wdn.shape) == (64, 2 * r, 32), wdn.shape
+    with torch.inference_mode():
+        x = orc.sconv1d(wav.unsqueeze(1), ENC + "0.conv.conv")
+        want = orc.sconv1d(F.elu(orc.resblock(x, ENC + "1")), ENC + "3.conv.conv", stride=r)
+    dev = lambda t: t.cuda().contiguous()
+    args = list(map(dev, (wav, e0w, e0b, w3, b3, w1.reshape(32, 16), b1, ws.reshape(32, 32), bs, wdn, bdn)))
+    y = torch.full((B, T // r, 64), float("nan"), device="cuda")
+    check(lib.wt_resblock_down(*[_ptr(t) for t in args], _ptr(y), B, T, r, None), "wt_resblock_down")
+    torch.cuda.synchronize()
+    assert tuple(want.shape) == (B, 64, T // r), want.shape
+    got = y.permute(0, 2, 1).cpu().numpy()
+    err = rel_l2(got, want.numpy())
+    edge = max(rel_l2(got[:, :, :2], want.numpy()[:, :, :2]), rel_l2(got[:, :, -2:], want.numpy()[:, :, -2:]))
+    parity_log.record(f"resblock16_down[{arch},T={T}]", rel_l2=err, edge_rel_l2=edge)
+    assert err < 1e-5 and edge < 1e-5, (arch, T, err, edge)
 
 
 @pytest.mark.parametrize("mode", ["persistent", "step"])

@@ -21,7 +21,7 @@ EXPORTS = [
     "wt_plan_find_buffer", "wt_plan_buffer_info", "wt_plan_buffer_name", "wt_plan_status", "wt_plan_num_steps", "wt_plan_step_name",
     "wt_plan_set_timing", "wt_plan_read_timing", "wt_model_split_ok", "wt_model_take_bad_codes", "wt_encode", "wt_codes_to_features",
     "wt_decode", "wt_seanet_decode", "wt_head", "wt_unit_run", "wt_sconv1d", "wt_linear", "wt_conv1d_s32", "wt_vq_workspace_bytes",
-    "wt_vq_nearest", "wt_vq_nearest_f32", "wt_resblock",
+    "wt_vq_nearest", "wt_vq_nearest_f32", "wt_resblock", "wt_resblock_down",
     "wt_resampler_create", "wt_resampler_destroy", "wt_resampler_out_length", "wt_convert_audio", "wt_pcm16",
     "wt_linear_overlap_add",
 ]
@@ -109,6 +109,7 @@ def _load() -> ctypes.CDLL:
     lib.wt_vq_nearest.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
     lib.wt_vq_nearest_f32.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
     lib.wt_resblock.argtypes = [c_void_p] * 11 + [c_int32, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]
+    lib.wt_resblock_down.argtypes = [c_void_p] * 12 + [c_int32, c_int64, c_int32, c_void_p]
     lib.wt_resampler_create.argtypes = [c_int32, c_int32, c_int32, POINTER(c_void_p)]
     lib.wt_resampler_destroy.argtypes = [c_void_p]
     lib.wt_resampler_destroy.restype = None

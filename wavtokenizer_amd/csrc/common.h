@@ -239,10 +239,18 @@ struct ResblockArgs {
     int out_s32;          // resblock16 only: write y in the S32 split-f16 layout (gemm16s.hip) instead of fp32
     int dbg;              // resblock16 timing experiments only (WT_RB16_DBG)
     unsigned* status;     // resblock16: call status word (range report of its split-f16 conversions); launcher default: g_launch
+    // resblock16 with the stage's down conv fused in (launch_resblock16_down): Wd [64][2R][32] folded, bd [64], stride R,
+    // y_down [B][T / R][64] fp32 is the only output
+    const float* Wd;
+    const float* bd;
+    float* y_down;
+    int R;
 };
 bool resblock_fusable(int C);
 int launch_resblock(const ResblockArgs& a, hipStream_t s);      // fp32 MFMA chain (resblock.hip)
 int launch_resblock16(const ResblockArgs& a, hipStream_t s);    // split-f16 MFMAs, fp32-equivalent (resblock16.hip)
+bool resblock16_down_fusable(int C, long T, int r, int k);
+int launch_resblock16_down(const ResblockArgs& a, hipStream_t s);   // stage 1 + ELU + down conv in one launch
 int launch_convtr(const float* x, const float* w /*[k][Cin][Cout]*/, const float* bias, float* y, int B, int Tin,
                   int Cin, int Cout, int k, int stride, int elu_in, hipStream_t s);
 

@@ -259,6 +259,27 @@ int build_encode(wt_plan* P) {
         const bool ws32 = s32 && (st.C % 32 == 0) && M->s32.count(st.down.w) &&
                           (fused || (M->s32.count(st.c3.w) && M->s32.count(st.c1.w) && M->s32.count(st.sc.w)));
         bool x_is_s32;                   // the resblock output (elu'd) is S32
+        // stage 1 of the shipped plan: first conv + resblock + ELU + down conv in ONE kernel, the stage's activations never
+        // leave LDS (resblock16.hip, DOWN).  WT_RB16_DOWN=0 keeps the two launches (A/B timing).
+        static const bool down_env = [] { const char* e = getenv("WT_RB16_DOWN"); return !e || e[0] != '0'; }();
+        const bool fuse_down = down_env && fused && idx == 1 && fold_e0 && ws32 &&
+                               si + 1 < M->stages.size() && resblock_fusable(M->stages[si + 1].C) && st.down.cin == 32 &&
+                               st.down.cout == 64 && resblock16_down_fusable(st.C, Tc, st.r, st.down.k);
+        if (fuse_down) {
+            const long Td = Tc / st.r;
+            const int y = P->buf("enc." + std::to_string(idx + 2), (size_t)B * Td * st.down.cout);
+            P->step({-1, y}, [=](const RunCtx& c) {
+                ResblockArgs a{};
+                a.wav = c.in_f; a.e0_w = M->e0_w; a.e0_b = M->e0_b;
+                a.W3 = st.c3.w; a.b3 = st.c3.b; a.W1 = st.c1.w; a.b1 = st.c1.b; a.Ws = st.sc.w; a.bs = st.sc.b;
+                a.Wd = st.down.w; a.bd = st.down.b; a.y_down = P->ptr(c, y); a.R = st.r;
+                a.B = B; a.T = (int)Tc; a.C = st.C;
+                return launch_resblock16_down(a, c.stream);
+            }, 1, "resblock.fused_down");
+            x_raw = x_elu = -1;
+            x = y; Tc = Td; idx += 3;
+            continue;
+        }
         if (fused) {
             x = plan_resblock(P, st.c3, st.c1, st.sc, B, Tc, x, "enc." + std::to_string(idx), fuse_elu,
                               (idx == 1 && fold_e0) ? M : nullptr, 0, 0, ws32);

@@ -84,9 +84,19 @@ __device__ __forceinline__ int rb16_woff(int rows, int ks, int hl, int n, int h)
     return ((ks * 2 + hl) * rows + n) * 32 + ((h ^ ((n >> 3) & 1)) * 16);
 }
 
-// DBG: timing-experiment build (WT_RB16_DBG); the shipped instantiations test nothing at run time
-template <int C, int ROWS, int FOLD, bool DBG = false>
-__global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs a) {
+// DBG: timing-experiment build (WT_RB16_DBG); the shipped instantiations test nothing at run time.
+// DOWN = r > 0 (C = 32 with the folded first conv only): the stage's down conv — ELU, SConv1d(32 -> 64, k = 2r, stride r,
+// reflect; seanet.py:123-127) — is computed from the tile's output while it is still in LDS, and only ITS output
+// (64 channels at 1/r of the frame rate) goes to HBM: the 590 MB of stage-1 activations are neither written nor read back.
+// A tile is the 128-frame window [i*OPT*r - r/2, + 128) that OPT = (128 - 2r)/r + 1 consecutive output frames need
+// (31 for r = 4, 63 for r = 2: consecutive windows overlap by r frames, 3 % recomputed); wave w owns output channels
+// [16 w, 16 w + 16) with its 2r x 32 weights resident in registers as v_mfma_f32_16x16x32_f16 operands.
+template <int C, int ROWS, int FOLD, bool DBG = false, int DOWN = 0>
+__global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(const ResblockArgs a) {
+    static_assert(DOWN == 0 || (C == 32 && ROWS == 128 && FOLD == 1 && (DOWN == 2 || DOWN == 4)), "fused down conv: stage 1 only");
+    constexpr int DK = 2 * DOWN;                                     // down conv taps
+    constexpr int OPT = DOWN ? (ROWS - DK) / DOWN + 1 : 0;           // output frames per tile
+    constexpr int DMT = (OPT + 15) / 16;                             // 16-frame MFMA row tiles of the down conv
     using L = Rb16Layout<C, ROWS>;
     using XR = RbRow<C>;
     using HR = RbRow<L::H>;
@@ -99,6 +109,7 @@ __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs
     char* w2 = smem16 + L::off_w2;
     float* bb = reinterpret_cast<float*>(smem16 + L::off_b);
     float* wtile = reinterpret_cast<float*>(smem16 + L::off_wav);
+    float* e0s = reinterpret_cast<float*>(smem16 + L::total);        // DOWN: first-conv taps [7][32] and bias [32] (the registers go to the down conv)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float amax = 0.f, wmax = 0.f;        // largest activation / weight magnitude converted to the split-f16 form
 
@@ -129,7 +140,9 @@ __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs
         bb[e] = e < L::N1 ? (e < L::H ? a.b3[e] : 0.f) : (a.b1[e - L::N1] + a.bs[e - L::N1]);
 
     const long xbs = a.x_bstride ? a.x_bstride : (long)a.T * C;
-    const int tiles_per_clip = (a.T + ROWS - 1) / ROWS;
+    const int Tdown = DOWN ? a.T / (DOWN ? DOWN : 1) : 0;            // host: T % r == 0
+    const int tiles_per_clip = DOWN ? (Tdown + OPT - 1) / (OPT ? OPT : 1) : (a.T + ROWS - 1) / ROWS;
+    auto tile_t0 = [&](int ti) { return DOWN ? ti * OPT * DOWN - DOWN / 2 : ti * ROWS; };
     const long n_tiles = (long)a.B * tiles_per_clip;
     const int Tp1 = a.T > 1 ? a.T : 2;               // reflect pad 1 (k=3): conv.py:86-91
     const int Tp3 = a.T > 3 ? a.T : 4;               // reflect pad 3 (k=7)
@@ -143,7 +156,7 @@ __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs
     float pw = 0.f;
     auto prefetch = [&](long tile) {
         const int b = (int)(tile / tiles_per_clip);
-        const int t0 = (int)(tile - (long)b * tiles_per_clip) * ROWS;
+        const int t0 = tile_t0((int)(tile - (long)b * tiles_per_clip));
         if (FOLD) {
             if (tid < WAVN) {                                        // sample index t0 - 4 + tid, k=7 reflect
                 int p = t0 - 4 + tid;
@@ -189,14 +202,56 @@ __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs
     // folded first conv: this thread always fills the same 8 channels, so its 7 x 8 taps live in registers
     static_assert(NT % CPR == 0, "an item's channel chunk must be fixed per thread");
     const int c8_fixed = (tid % CPR) * 8;
-    float e0w[FOLD ? 7 : 1][8], e0b[8];
-    if (FOLD) {
+    float e0w[(FOLD && !DOWN) ? 7 : 1][8], e0b[8];
+    if (FOLD && !DOWN) {
 #pragma unroll
         for (int j = 0; j < 7; ++j)
 #pragma unroll
             for (int i = 0; i < 8; ++i) e0w[j][i] = a.e0_w[j * C + c8_fixed + i];
 #pragma unroll
         for (int i = 0; i < 8; ++i) e0b[i] = a.e0_b[c8_fixed + i];
+    }
+    if (DOWN) {
+        for (int e = tid; e < 8 * C; e += NT) e0s[e] = e < 7 * C ? a.e0_w[e] : a.e0_b[e - 7 * C];
+    }
+    // first-conv taps of this thread's 8 channels: registers, or (DOWN) two 16-byte LDS reads per tap (a wave reads four
+    // distinct addresses: broadcast)
+    auto e0_tap = [&](int j, float* w8) {
+        if (DOWN) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(e0s + j * C + c8_fixed), w1 = *reinterpret_cast<const f32x4*>(e0s + j * C + c8_fixed + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { w8[i] = w0[i]; w8[4 + i] = w1[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w8[i] = e0w[(FOLD && !DOWN) ? j : 0][i];
+        }
+    };
+    auto e0_bias = [&](float* v) {
+        if (DOWN) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(e0s + 7 * C + c8_fixed), w1 = *reinterpret_cast<const f32x4*>(e0s + 7 * C + c8_fixed + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[i] = w0[i]; v[4 + i] = w1[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = e0b[i];
+        }
+    };
+    // DOWN: this wave's down-conv weights, W[16 wave + n16][tap][8 q .. 8 q + 7] as (hi, lo) fragments per tap
+    f16x8 wdh[DOWN ? DK : 1], wdl[DOWN ? DK : 1];
+    float bd4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (DOWN) {
+        const int n16 = lane & 15, q = lane >> 4;
+#pragma unroll
+        for (int j = 0; j < DK; ++j) {
+            const float* src = a.Wd + ((long)(16 * wave + n16) * DK + j) * C + 8 * q;
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(src), w1 = *reinterpret_cast<const f32x4*>(src + 4);
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[i] = w0[i]; v[4 + i] = w1[i]; }
+            rb16_split8(v, wdh[DOWN ? j : 0], wdl[DOWN ? j : 0], wmax);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bd4[i] = a.bd[16 * wave + 4 * q + i];
     }
 
     const int fl = lane & 31, fh = lane >> 5;        // MFMA lane: (row or column fl, k half fh)
@@ -206,7 +261,8 @@ __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs
 
     for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int b = (int)(tile / tiles_per_clip);
-        const int t0 = (int)(tile - (long)b * tiles_per_clip) * ROWS;
+        const int ti = (int)(tile - (long)b * tiles_per_clip);
+        const int t0 = tile_t0(ti);
         __syncthreads();                             // previous tile fully consumed (and weights landed)
         if (dbg & 1) { __syncthreads(); } else
         if (FOLD) {
@@ -219,21 +275,21 @@ __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs
                 const int r = e / CPR;               // the 8-channel chunk of an item is fixed per thread (NT % CPR == 0)
                 float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 if (interior) {                      // x row r = frame t0-1+r needs samples wtile[r .. r+6]
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = e0b[i];
+                    e0_bias(v);
 #pragma unroll
                     for (int j = 0; j < 7; ++j) {
                         const float xv = wtile[r + j];
+                        float w8[8];
+                        e0_tap(j, w8);
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) v[i] += xv * e0w[j][i];
+                        for (int i = 0; i < 8; ++i) v[i] += xv * w8[i];
                     }
                 } else {
                     int pos = t0 - 1 + r;            // frame of this x row, k=3 reflect
                     pos = pos < 0 ? -pos : pos;
                     pos = pos >= Tp1 ? 2 * (Tp1 - 1) - pos : pos;
                     if (pos >= 0 && pos < a.T) {
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) v[i] = e0b[i];
+                        e0_bias(v);
 #pragma unroll
                         for (int j = 0; j < 7; ++j) {
                             // the staged window holds raw positions t0-4 .. t0+ROWS+3; a reflected frame near a clip
@@ -246,8 +302,10 @@ __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs
                                 const int wi = p - (t0 - 4);
                                 xv = (direct && wi >= 0 && wi < WAVN) ? wtile[wi] : a.wav[(long)b * a.T + p];
                             }
+                            float w8[8];
+                            e0_tap(j, w8);
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) v[i] += xv * e0w[j][i];
+                            for (int i = 0; i < 8; ++i) v[i] += xv * w8[i];
                         }
                     }
                 }
@@ -354,9 +412,9 @@ __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         v[i] = a2m[j][4 * g + i] + a2c[j][4 * g + i] * LO_SCALE + bb[L::N1 + n + i];
-                        if (a.elu_out) v[i] = rb16_elu(v[i]);
+                        if (DOWN || a.elu_out) v[i] = rb16_elu(v[i]);
                     }
-                    if (a.out_s32) {                                // S32: chunk (n/32)*8 + n%32/8 holds hi, + 4 holds lo
+                    if (DOWN || a.out_s32) {                        // S32: chunk (n/32)*8 + n%32/8 holds hi, + 4 holds lo
                         f16x4 hi, lo;
                         rb16_split4(v, hi, lo, amax);
                         const int ch = (n >> 5) * 8 + ((n & 31) >> 3);
@@ -366,6 +424,7 @@ __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs
                         *reinterpret_cast<f32x4*>(st + fl * XR::bytes + (((n >> 2) ^ XR::swz(fl)) * 16)) = v;
                     }
                 }
+            if constexpr (DOWN == 0) {
             constexpr int LPR = XR::chunks;                         // lanes per row: 8 (C = 32) or 16 (C = 64)
             constexpr int RPI = 64 / LPR;                           // rows per store instruction
             const long tbase = (long)b * a.T + t0 + row0;
@@ -374,6 +433,40 @@ __global__ __launch_bounds__(ROWS * 2) void resblock16_kernel(const ResblockArgs
                 const int r = it * RPI + lane / LPR, ch = lane % LPR;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(st + r * XR::bytes + ((ch ^ XR::swz(r)) * 16));
                 if (t0 + row0 + r < a.T && !(dbg & 4)) *reinterpret_cast<f32x4*>(a.y + (tbase + r) * C + ch * 4) = v;
+            }
+            }
+        }
+        if constexpr (DOWN > 0) {
+            // ---- down conv on the tile: out[n][o] = bd[n] + sum over (tap j, ci) Wd[n][j][ci] * elu(y)[o * r - r/2 + j][ci], the
+            // S32(elu(y)) image of all 128 frames sitting in xr.  Reflect padding (conv.py:79-96; T % r == 0 and T > 2r: host)
+            // maps the few positions beyond a clip edge back into this tile's window.
+            __syncthreads();                                        // every wave's rows of y are staged
+            const int m16 = lane & 15, q = lane >> 4;
+#pragma unroll 1                                                    // (unrolled, hipcc hoists every tap's fragment reads: registers)
+            for (int mt = 0; mt < DMT; ++mt) {
+                const int o = 16 * mt + m16;
+                const int t_out = ti * OPT + o;
+                const bool valid = o < OPT && t_out < Tdown;
+                f32x4 dm = {0.f, 0.f, 0.f, 0.f}, dc = dm;
+#pragma unroll
+                for (int j = 0; j < DK; ++j) {
+                    int pos = t_out * DOWN - DOWN / 2 + j;
+                    pos = pos < 0 ? -pos : pos;
+                    pos = pos >= a.T ? 2 * (a.T - 1) - pos : pos;
+                    int row = valid ? pos - t0 : 0;
+                    row = row < 0 ? 0 : (row > ROWS - 1 ? ROWS - 1 : row);
+                    const f16x8 yh = *reinterpret_cast<const f16x8*>(xr + XR::off(row, 8 * q, 0));
+                    const f16x8 yl = *reinterpret_cast<const f16x8*>(xr + XR::off(row, 8 * q, 1));
+                    dm = __builtin_amdgcn_mfma_f32_16x16x32_f16(wdh[DOWN ? j : 0], yh, dm, 0, 0, 0);
+                    dc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wdl[DOWN ? j : 0], yh, dc, 0, 0, 0);
+                    dc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wdh[DOWN ? j : 0], yl, dc, 0, 0, 0);
+                }
+                if (valid && !(dbg & 4)) {
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = dm[i] + dc[i] * LO_SCALE + bd4[i];
+                    *reinterpret_cast<f32x4*>(a.y_down + ((long)b * Tdown + t_out) * 64 + 16 * wave + 4 * q) = v;
+                }
             }
         }
     }
@@ -405,6 +498,37 @@ static int launch_rb16(const ResblockArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(ROWS * 2), smem, s, b);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+// stage 1 with the down conv fused in: wav [B][T] -> y_down [B][T / r][64] fp32 (r = a.R = 2 or 4)
+template <int R>
+static int launch_rb16_down(const ResblockArgs& a, hipStream_t s) {
+    static PerDeviceOnce attr_once;
+    constexpr size_t smem = (size_t)Rb16Layout<32, 128>::total + 1024;
+    constexpr int OPT = (128 - 2 * R) / R + 1;
+    auto kern = resblock16_kernel<32, 128, 1, false, R>;
+    if (int rc = attr_once.run([&]() -> int {
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        return 0;
+    })) return rc;
+    const long tiles = (long)a.B * ((a.T / R + OPT - 1) / OPT);
+    const int per_cu = (int)(160 * 1024 / smem) < 4 ? (int)(160 * 1024 / smem) : 4;
+    const long grid = tiles < 256L * per_cu ? tiles : 256L * per_cu;
+    ResblockArgs b = a;
+    b.dbg = 0;
+    if (!b.status) b.status = g_launch.status;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, s, b);
+    WT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+bool resblock16_down_fusable(int C, long T, int r, int k) { return C == 32 && (r == 2 || r == 4) && k == 2 * r && T % r == 0 && T >= 1024; }
+
+int launch_resblock16_down(const ResblockArgs& a, hipStream_t s) {
+    if (!a.wav || !a.Wd || !a.bd || !a.y_down || !resblock16_down_fusable(a.C, a.T, a.R, 2 * a.R)) {
+        set_error("resblock16_down: needs the waveform, C = 32, stride 2 or 4 with k = 2 * stride, T % stride == 0, T >= 1024"); return -1;
+    }
+    return a.R == 4 ? launch_rb16_down<4>(a, s) : launch_rb16_down<2>(a, s);
 }
 
 int launch_resblock16(const ResblockArgs& a, hipStream_t s) {
