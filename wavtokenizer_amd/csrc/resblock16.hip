@@ -112,6 +112,23 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
     float* e0s = reinterpret_cast<float*>(smem16 + L::total);        // DOWN: first-conv taps [7][32] and bias [32] (the registers go to the down conv)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float amax = 0.f, wmax = 0.f;        // largest activation / weight magnitude converted to the split-f16 form
+    // Byte offset in xr of the 16-byte chunk `chunk` (0 .. C/4 - 1: hi chunks, then lo, per 32 channels) of frame row r.
+    // DOWN: frame r = R o + j sits at row j * (ROWS / R) + o ("planes" of equal tap phase) and its chunks are XORed with
+    // ((o >> 1) ^ j * (8 / R)) & 7, so that BOTH 16 consecutive frames (shortcut conv, tile fill, staging) and 16 frames a
+    // stride R apart (one tap of the down conv for 16 output frames) cover all 64 banks.
+    auto xr_chunk_off = [&](int r, int chunk) -> int {
+        if constexpr (DOWN > 0) {
+            const int o = r / DOWN, j = r % DOWN;
+            const int g = ((o >> 1) ^ (j * (8 / DOWN))) & 7;
+            return (j * (ROWS / DOWN) + o) * XR::bytes + ((chunk ^ g) * 16);
+        } else {
+            return r * XR::bytes + ((chunk ^ XR::swz(r)) * 16);
+        }
+    };
+    auto xr_off = [&](int r, int ci, int lo) -> int {              // the 8-half chunk of channels ci .. ci + 7 (cf. RbRow::off)
+        constexpr int G = C < 32 ? C : 32;
+        return xr_chunk_off(r, (ci / G) * (G / 4) + lo * (G / 8) + (ci % G) / 8);
+    };
 
     // ---- resident split weights.  W3 [H][3][C] -> rows n < H (n >= H: zero padding), k = tap*C + ci;
     //      W2 = [W1 (C x H) | Ws (C x C)] -> rows n < C, k < H from conv1, then the shortcut
@@ -187,12 +204,12 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
         f16x8 hi, lo;
         if (r >= 1 && r <= ROWS) {
             rb16_split8(v, hi, lo, amax);
-            *reinterpret_cast<f16x8*>(xr + XR::off(r - 1, c8, 0)) = hi;
-            *reinterpret_cast<f16x8*>(xr + XR::off(r - 1, c8, 1)) = lo;
+            *reinterpret_cast<f16x8*>(xr + xr_off(r - 1, c8, 0)) = hi;
+            *reinterpret_cast<f16x8*>(xr + xr_off(r - 1, c8, 1)) = lo;
         }
         float ev[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ev[i] = rb16_elu(v[i]);
+        for (int i = 0; i < 8; ++i) ev[i] = (DBG && (a.dbg & 16)) ? v[i] : rb16_elu(v[i]);
         float unused = 0.f;                  // |elu(v)| <= |v|, which the raw split above has covered (or, for the halo rows, a neighbouring tile's)
         rb16_split8(ev, hi, lo, unused);
         *reinterpret_cast<f16x8*>(xe + XR::off(r, c8, 0)) = hi;
@@ -256,7 +273,7 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
 
     const int fl = lane & 31, fh = lane >> 5;        // MFMA lane: (row or column fl, k half fh)
     const int row0 = wave * 32;                      // this wave's frames inside the tile
-    const int dbg = DBG ? a.dbg : 0;                 // timing experiments only (WT_RB16_DBG): 1 no tile fill, 2 no MFMA, 4 no store
+    const int dbg = DBG ? a.dbg : 0;                 // timing experiments only (WT_RB16_DBG): 1 no tile fill, 2 no MFMA, 4 no store, 8 no down-conv taps, 16 no ELU
     constexpr float LO_SCALE = 1.f / 2048.f;
 
     for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -361,7 +378,10 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
                     f32x4 v;
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        v[i] = rb16_elu(a1m[j][4 * g + i] + a1c[j][4 * g + i] * LO_SCALE + bb[n + i]);
+                        v[i] = a1m[j][4 * g + i] + a1c[j][4 * g + i] * LO_SCALE + bb[n + i];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (!(dbg & 16)) v[i] = rb16_elu(v[i]);
                     f16x4 hi, lo;
                     rb16_split4(v, hi, lo, amax);
                     *reinterpret_cast<f16x4*>(he + HR::off(row0 + fl, n & ~7, 0) + (n & 7) * 2) = hi;
@@ -386,8 +406,8 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
                 bl = *reinterpret_cast<const f16x8*>(he + HR::off(row0 + fl, ks * 16 + 8 * fh, 1));
             } else {
                 const int ci = ks * 16 - L::H + 8 * fh;
-                bh = *reinterpret_cast<const f16x8*>(xr + XR::off(row0 + fl, ci, 0));
-                bl = *reinterpret_cast<const f16x8*>(xr + XR::off(row0 + fl, ci, 1));
+                bh = *reinterpret_cast<const f16x8*>(xr + xr_off(row0 + fl, ci, 0));
+                bl = *reinterpret_cast<const f16x8*>(xr + xr_off(row0 + fl, ci, 1));
             }
 #pragma unroll
             for (int j = 0; j < TN2; ++j) {
@@ -402,7 +422,7 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
         // the tile is staged in the wave's own xr rows (free now: the shortcut was their last reader, and they are
         // private to the wave) and written out with every lane storing 16 bytes of a full 128-byte line.
         {
-            char* st = xr + row0 * XR::bytes;                       // 32 rows x C*4 bytes, chunk-swizzled like xr
+            char* st = xr + row0 * XR::bytes;                       // 32 rows x C*4 bytes, chunk-swizzled like xr (DOWN: the wave's rows of the plane layout)
 #pragma unroll
             for (int j = 0; j < TN2; ++j)
 #pragma unroll
@@ -412,14 +432,14 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         v[i] = a2m[j][4 * g + i] + a2c[j][4 * g + i] * LO_SCALE + bb[L::N1 + n + i];
-                        if (DOWN || a.elu_out) v[i] = rb16_elu(v[i]);
+                        if ((DOWN || a.elu_out) && !(dbg & 16)) v[i] = rb16_elu(v[i]);
                     }
                     if (DOWN || a.out_s32) {                        // S32: chunk (n/32)*8 + n%32/8 holds hi, + 4 holds lo
                         f16x4 hi, lo;
                         rb16_split4(v, hi, lo, amax);
                         const int ch = (n >> 5) * 8 + ((n & 31) >> 3);
-                        *reinterpret_cast<f16x4*>(st + fl * XR::bytes + ((ch ^ XR::swz(fl)) * 16) + (n & 7) * 2) = hi;
-                        *reinterpret_cast<f16x4*>(st + fl * XR::bytes + (((ch + 4) ^ XR::swz(fl)) * 16) + (n & 7) * 2) = lo;
+                        *reinterpret_cast<f16x4*>(xr + xr_chunk_off(row0 + fl, ch) + (n & 7) * 2) = hi;
+                        *reinterpret_cast<f16x4*>(xr + xr_chunk_off(row0 + fl, ch + 4) + (n & 7) * 2) = lo;
                     } else {                                        // fp32: chunk n/4
                         *reinterpret_cast<f32x4*>(st + fl * XR::bytes + (((n >> 2) ^ XR::swz(fl)) * 16)) = v;
                     }
@@ -442,24 +462,42 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
             // maps the few positions beyond a clip edge back into this tile's window.
             __syncthreads();                                        // every wave's rows of y are staged
             const int m16 = lane & 15, q = lane >> 4;
+            // a tile whose taps all lie inside the clip reads frame o * r + j for output o, tap j: with the plane layout
+            // that is a per-lane base (two of them: j < r, j >= r) XOR a constant, plus an immediate
+            const int last_o = (ti * OPT + OPT <= Tdown ? ti * OPT + OPT : Tdown) - 1;
+            const bool inner = ti > 0 && last_o * DOWN - DOWN / 2 + DK - 1 < a.T;
 #pragma unroll 1                                                    // (unrolled, hipcc hoists every tap's fragment reads: registers)
             for (int mt = 0; mt < DMT; ++mt) {
                 const int o = 16 * mt + m16;
                 const int t_out = ti * OPT + o;
                 const bool valid = o < OPT && t_out < Tdown;
                 f32x4 dm = {0.f, 0.f, 0.f, 0.f}, dc = dm;
+                if (dbg & 8) {
+                } else if (inner) {
 #pragma unroll
-                for (int j = 0; j < DK; ++j) {
-                    int pos = t_out * DOWN - DOWN / 2 + j;
-                    pos = pos < 0 ? -pos : pos;
-                    pos = pos >= a.T ? 2 * (a.T - 1) - pos : pos;
-                    int row = valid ? pos - t0 : 0;
-                    row = row < 0 ? 0 : (row > ROWS - 1 ? ROWS - 1 : row);
-                    const f16x8 yh = *reinterpret_cast<const f16x8*>(xr + XR::off(row, 8 * q, 0));
-                    const f16x8 yl = *reinterpret_cast<const f16x8*>(xr + XR::off(row, 8 * q, 1));
-                    dm = __builtin_amdgcn_mfma_f32_16x16x32_f16(wdh[DOWN ? j : 0], yh, dm, 0, 0, 0);
-                    dc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wdl[DOWN ? j : 0], yh, dc, 0, 0, 0);
-                    dc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wdh[DOWN ? j : 0], yl, dc, 0, 0, 0);
+                    for (int j = 0; j < DK; ++j) {
+                        const char* src = xr + mt * (16 * XR::bytes) + (j % DOWN) * (ROWS / DOWN) * XR::bytes;
+                        const int base = (m16 + j / DOWN) * XR::bytes + ((q ^ (((m16 + j / DOWN) >> 1) & 7)) * 16);
+                        const f16x8 yh = *reinterpret_cast<const f16x8*>(src + (base ^ (((j % DOWN) * (8 / DOWN)) * 16)));
+                        const f16x8 yl = *reinterpret_cast<const f16x8*>(src + (base ^ (((j % DOWN) * (8 / DOWN)) * 16) ^ 64));
+                        dm = __builtin_amdgcn_mfma_f32_16x16x32_f16(wdh[DOWN ? j : 0], yh, dm, 0, 0, 0);
+                        dc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wdl[DOWN ? j : 0], yh, dc, 0, 0, 0);
+                        dc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wdh[DOWN ? j : 0], yl, dc, 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < DK; ++j) {
+                        int pos = t_out * DOWN - DOWN / 2 + j;
+                        pos = pos < 0 ? -pos : pos;
+                        pos = pos >= a.T ? 2 * (a.T - 1) - pos : pos;
+                        int row = valid ? pos - t0 : 0;
+                        row = row < 0 ? 0 : (row > ROWS - 1 ? ROWS - 1 : row);
+                        const f16x8 yh = *reinterpret_cast<const f16x8*>(xr + xr_off(row, 8 * q, 0));
+                        const f16x8 yl = *reinterpret_cast<const f16x8*>(xr + xr_off(row, 8 * q, 1));
+                        dm = __builtin_amdgcn_mfma_f32_16x16x32_f16(wdh[DOWN ? j : 0], yh, dm, 0, 0, 0);
+                        dc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wdl[DOWN ? j : 0], yh, dc, 0, 0, 0);
+                        dc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wdh[DOWN ? j : 0], yl, dc, 0, 0, 0);
+                    }
                 }
                 if (valid && !(dbg & 4)) {
                     f32x4 v;
@@ -507,15 +545,21 @@ static int launch_rb16_down(const ResblockArgs& a, hipStream_t s) {
     constexpr size_t smem = (size_t)Rb16Layout<32, 128>::total + 1024;
     constexpr int OPT = (128 - 2 * R) / R + 1;
     auto kern = resblock16_kernel<32, 128, 1, false, R>;
+    int dbg_req = 0;
+    if (const char* e = getenv("WT_RB16_DBG")) dbg_req = atoi(e);
+    if (dbg_req) kern = resblock16_kernel<32, 128, 1, true, R>;
     if (int rc = attr_once.run([&]() -> int {
-        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock16_kernel<32, 128, 1, false, R>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock16_kernel<32, 128, 1, true, R>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         return 0;
     })) return rc;
     const long tiles = (long)a.B * ((a.T / R + OPT - 1) / OPT);
     const int per_cu = (int)(160 * 1024 / smem) < 4 ? (int)(160 * 1024 / smem) : 4;
     const long grid = tiles < 256L * per_cu ? tiles : 256L * per_cu;
     ResblockArgs b = a;
-    b.dbg = 0;
+    b.dbg = dbg_req;
     if (!b.status) b.status = g_launch.status;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, s, b);
     WT_HIP_CHECK(hipGetLastError());
