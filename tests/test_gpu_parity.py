@@ -675,7 +675,7 @@ def _fold(sd, prefix):
 ENC = "feature_extractor.encodec.encoder.model."
 
 
-@pytest.mark.parametrize("T", [1, 2, 127, 128, 129, 18000])
+@pytest.mark.parametrize("T", [1, 2, 126, 127, 128, 129, 18000])
 @pytest.mark.parametrize("stage,fold", [(1, True), (1, False), (4, False)])
 def test_resblock16_kernel_against_oracle(stage, fold, T):
     """resblock16_kernel (the fused SEANetResnetBlock the encoder plan launches: C = 32 with the first conv folded into

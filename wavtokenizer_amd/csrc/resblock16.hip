@@ -95,7 +95,10 @@ template <int C, int ROWS, int FOLD, bool DBG = false, int DOWN = 0>
 __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(const ResblockArgs a) {
     static_assert(DOWN == 0 || (C == 32 && ROWS == 128 && FOLD == 1 && (DOWN == 2 || DOWN == 4)), "fused down conv: stage 1 only");
     constexpr int DK = 2 * DOWN;                                     // down conv taps
-    constexpr int OPT = DOWN ? (ROWS - DK) / DOWN + 1 : 0;           // output frames per tile
+    // FOLD: the tile fill is one MFMA pass of 32 x-rows per wave, so the tile is ROWS x-rows INCLUDING the k=3 halo and
+    // yields ROWS - 2 frames of y (the last two MFMA columns of conv3 read two zero rows and are dropped)
+    constexpr int VALID = FOLD ? ROWS - 2 : ROWS;
+    constexpr int OPT = DOWN ? (VALID - DK) / DOWN + 1 : 0;          // output frames per tile
     constexpr int DMT = (OPT + 15) / 16;                             // 16-frame MFMA row tiles of the down conv
     using L = Rb16Layout<C, ROWS>;
     using XR = RbRow<C>;
@@ -109,7 +112,6 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
     char* w2 = smem16 + L::off_w2;
     float* bb = reinterpret_cast<float*>(smem16 + L::off_b);
     float* wtile = reinterpret_cast<float*>(smem16 + L::off_wav);
-    float* e0s = reinterpret_cast<float*>(smem16 + L::total);        // DOWN: first-conv taps [7][32] and bias [32] (the registers go to the down conv)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float amax = 0.f, wmax = 0.f;        // largest activation / weight magnitude converted to the split-f16 form
     // Byte offset in xr of the 16-byte chunk `chunk` (0 .. C/4 - 1: hi chunks, then lo, per 32 channels) of frame row r.
@@ -158,8 +160,8 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
 
     const long xbs = a.x_bstride ? a.x_bstride : (long)a.T * C;
     const int Tdown = DOWN ? a.T / (DOWN ? DOWN : 1) : 0;            // host: T % r == 0
-    const int tiles_per_clip = DOWN ? (Tdown + OPT - 1) / (OPT ? OPT : 1) : (a.T + ROWS - 1) / ROWS;
-    auto tile_t0 = [&](int ti) { return DOWN ? ti * OPT * DOWN - DOWN / 2 : ti * ROWS; };
+    const int tiles_per_clip = DOWN ? (Tdown + OPT - 1) / (OPT ? OPT : 1) : (a.T + VALID - 1) / VALID;
+    auto tile_t0 = [&](int ti) { return DOWN ? ti * OPT * DOWN - DOWN / 2 : ti * VALID; };
     const long n_tiles = (long)a.B * tiles_per_clip;
     const int Tp1 = a.T > 1 ? a.T : 2;               // reflect pad 1 (k=3): conv.py:86-91
     const int Tp3 = a.T > 3 ? a.T : 4;               // reflect pad 3 (k=7)
@@ -216,42 +218,26 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
         *reinterpret_cast<f16x8*>(xe + XR::off(r, c8, 1)) = lo;
     };
     if ((long)blockIdx.x < n_tiles) prefetch(blockIdx.x);
-    // folded first conv: this thread always fills the same 8 channels, so its 7 x 8 taps live in registers
-    static_assert(NT % CPR == 0, "an item's channel chunk must be fixed per thread");
-    const int c8_fixed = (tid % CPR) * 8;
-    float e0w[(FOLD && !DOWN) ? 7 : 1][8], e0b[8];
-    if (FOLD && !DOWN) {
+    // Folded first conv (seanet.py:117: SConv1d(1 -> 32, k = 7)) as a split-f16 MFMA: x[ch][frame] = sum over k of
+    // A[ch][k] B[k][frame] with k = 0 .. 6 the taps, k = 7 the bias against a constant 1, k = 8 .. 15 zero.  This lane's A
+    // fragment (channel fl, k half fh) stays in registers.
+    f16x8 e0h = {0, 0, 0, 0, 0, 0, 0, 0}, e0l = e0h;
+    if (FOLD) {
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if ((lane >> 5) == 0) {
 #pragma unroll
-        for (int j = 0; j < 7; ++j)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) e0w[j][i] = a.e0_w[j * C + c8_fixed + i];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) e0b[i] = a.e0_b[c8_fixed + i];
-    }
-    if (DOWN) {
-        for (int e = tid; e < 8 * C; e += NT) e0s[e] = e < 7 * C ? a.e0_w[e] : a.e0_b[e - 7 * C];
-    }
-    // first-conv taps of this thread's 8 channels: registers, or (DOWN) two 16-byte LDS reads per tap (a wave reads four
-    // distinct addresses: broadcast)
-    auto e0_tap = [&](int j, float* w8) {
-        if (DOWN) {
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(e0s + j * C + c8_fixed), w1 = *reinterpret_cast<const f32x4*>(e0s + j * C + c8_fixed + 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { w8[i] = w0[i]; w8[4 + i] = w1[i]; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) w8[i] = e0w[(FOLD && !DOWN) ? j : 0][i];
+            for (int j = 0; j < 7; ++j) v[j] = a.e0_w[j * C + (lane & 31)];
+            v[7] = a.e0_b[lane & 31];
         }
-    };
-    auto e0_bias = [&](float* v) {
-        if (DOWN) {
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(e0s + 7 * C + c8_fixed), w1 = *reinterpret_cast<const f32x4*>(e0s + 7 * C + c8_fixed + 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { v[i] = w0[i]; v[4 + i] = w1[i]; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = e0b[i];
-        }
+        rb16_split8(v, e0h, e0l, wmax);
+        for (int e = tid; e < 2 * XR::bytes / 16; e += NT)         // xe rows ROWS, ROWS + 1: zero, never written again
+            *reinterpret_cast<f32x4*>(xe + ROWS * XR::bytes + e * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // the reflect-padded waveform (conv.py:79-96) at padded position p of clip b; zero outside (clips shorter than the pad)
+    auto wav_pad = [&](int b, int p) -> float {
+        p = p < 0 ? -p : p;
+        p = p >= Tp3 ? 2 * (Tp3 - 1) - p : p;
+        return (p >= 0 && p < a.T) ? a.wav[(long)b * a.T + p] : 0.f;
     };
     // DOWN: this wave's down-conv weights, W[16 wave + n16][tap][8 q .. 8 q + 7] as (hi, lo) fragments per tap
     f16x8 wdh[DOWN ? DK : 1], wdl[DOWN ? DK : 1];
@@ -283,50 +269,60 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
         __syncthreads();                             // previous tile fully consumed (and weights landed)
         if (dbg & 1) { __syncthreads(); } else
         if (FOLD) {
-            // first encoder conv from the staged samples: x[f] = b + sum_j w[j] * wav[refl(f + j - 3)]
+            // first encoder conv from the staged samples: xe row r = frame t0 - 1 + r = b + sum_j w[j] * wavpad[frame + j - 3],
+            // wtile[i] = wavpad[t0 - 4 + i].  Wave w produces rows 32 w .. 32 w + 31: B fragment = the lane's 7 samples + 1.
             if (tid < WAVN) wtile[tid] = pw;
             __syncthreads();
-            const bool direct = (t0 - 4 >= 0) && (t0 + ROWS + 4 <= a.T);      // window not reflected itself
-            const bool interior = direct && (t0 + ROWS < a.T);                 // no reflected x row either
-            for (int e = tid; e < L::NX * CPR; e += NT) {
-                const int r = e / CPR;               // the 8-channel chunk of an item is fixed per thread (NT % CPR == 0)
-                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if (interior) {                      // x row r = frame t0-1+r needs samples wtile[r .. r+6]
-                    e0_bias(v);
+            const bool direct = (t0 - 4 >= 0) && (t0 + ROWS + 4 <= a.T);      // no reflected sample or frame in the window
+            const int r = row0 + fl;
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (direct) {
 #pragma unroll
-                    for (int j = 0; j < 7; ++j) {
-                        const float xv = wtile[r + j];
-                        float w8[8];
-                        e0_tap(j, w8);
+                for (int j = 0; j < 7; ++j) v[j] = wtile[r + j];
+                v[7] = 1.f;
+            } else {
+                int pos = t0 - 1 + r;                // frame of this x row, k=3 reflect
+                pos = pos < 0 ? -pos : pos;
+                pos = pos >= Tp1 ? 2 * (Tp1 - 1) - pos : pos;
+                if (pos >= 0 && pos < a.T) {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) v[i] += xv * w8[i];
+                    for (int j = 0; j < 7; ++j) {    // a reflected frame near a clip edge may need samples outside the window (rare)
+                        const int wi = pos + j - 3 - (t0 - 4);
+                        v[j] = (wi >= 0 && wi < WAVN) ? wtile[wi] : wav_pad(b, pos + j - 3);
                     }
-                } else {
-                    int pos = t0 - 1 + r;            // frame of this x row, k=3 reflect
-                    pos = pos < 0 ? -pos : pos;
-                    pos = pos >= Tp1 ? 2 * (Tp1 - 1) - pos : pos;
-                    if (pos >= 0 && pos < a.T) {
-                        e0_bias(v);
-#pragma unroll
-                        for (int j = 0; j < 7; ++j) {
-                            // the staged window holds raw positions t0-4 .. t0+ROWS+3; a reflected frame near a clip
-                            // edge may need samples outside it, which are re-read from memory (rare)
-                            int p = pos + j - 3;
-                            p = p < 0 ? -p : p;
-                            p = p >= Tp3 ? 2 * (Tp3 - 1) - p : p;
-                            float xv = 0.f;
-                            if (p >= 0 && p < a.T) {
-                                const int wi = p - (t0 - 4);
-                                xv = (direct && wi >= 0 && wi < WAVN) ? wtile[wi] : a.wav[(long)b * a.T + p];
-                            }
-                            float w8[8];
-                            e0_tap(j, w8);
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) v[i] += xv * w8[i];
-                        }
-                    }
+                    v[7] = 1.f;
                 }
-                put_item(r, c8_fixed, v);
+            }
+            f16x8 bh, bl;
+            rb16_split8(v, bh, bl, amax);
+            if (fh) { bh = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; bl = bh; }
+            f32x16 xm, xc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { xm[i] = 0.f; xc[i] = 0.f; }
+            xm = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0h, bh, xm, 0, 0, 0);
+            xc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0l, bh, xc, 0, 0, 0);
+            xc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0h, bl, xc, 0, 0, 0);
+            // lane: row r, channels 8 g + 4 fh .. + 3.  Raw split -> xr row r - 1 (row 0 has none: its lanes zero xr row ROWS - 1,
+            // which the invalid last MFMA column of the shortcut reads), elu split -> xe row r
+            const int xrow = r == 0 ? ROWS - 1 : r - 1;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = 8 * g + 4 * fh;
+                f32x4 x4, e4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float x = xm[4 * g + i] + xc[4 * g + i] * LO_SCALE;
+                    e4[i] = (DBG && (a.dbg & 16)) ? x : rb16_elu(x);
+                    x4[i] = r == 0 ? 0.f : x;
+                }
+                f16x4 hi, lo;
+                rb16_split4(x4, hi, lo, amax);
+                *reinterpret_cast<f16x4*>(xr + xr_off(xrow, n & ~7, 0) + (n & 7) * 2) = hi;
+                *reinterpret_cast<f16x4*>(xr + xr_off(xrow, n & ~7, 1) + (n & 7) * 2) = lo;
+                float unused = 0.f;              // |elu(x)| <= |x|
+                rb16_split4(e4, hi, lo, unused);
+                *reinterpret_cast<f16x4*>(xe + XR::off(r, n & ~7, 0) + (n & 7) * 2) = hi;
+                *reinterpret_cast<f16x4*>(xe + XR::off(r, n & ~7, 1) + (n & 7) * 2) = lo;
             }
         } else {
 #pragma unroll
@@ -452,7 +448,7 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
             for (int it = 0; it < 32 / RPI; ++it) {
                 const int r = it * RPI + lane / LPR, ch = lane % LPR;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(st + r * XR::bytes + ((ch ^ XR::swz(r)) * 16));
-                if (t0 + row0 + r < a.T && !(dbg & 4)) *reinterpret_cast<f32x4*>(a.y + (tbase + r) * C + ch * 4) = v;
+                if (row0 + r < VALID && t0 + row0 + r < a.T && !(dbg & 4)) *reinterpret_cast<f32x4*>(a.y + (tbase + r) * C + ch * 4) = v;
             }
             }
         }
@@ -527,7 +523,8 @@ static int launch_rb16(const ResblockArgs& a, hipStream_t s) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         return 0;
     })) return rc;
-    const long tiles = (long)a.B * ((a.T + ROWS - 1) / ROWS);
+    constexpr int VALID = FOLD ? ROWS - 2 : ROWS;
+    const long tiles = (long)a.B * ((a.T + VALID - 1) / VALID);
     const int per_cu = (int)(160 * 1024 / smem) < 4 ? (int)(160 * 1024 / smem) : 4;
     const long grid = tiles < 256L * per_cu ? tiles : 256L * per_cu;
     ResblockArgs b = a;
@@ -542,8 +539,8 @@ static int launch_rb16(const ResblockArgs& a, hipStream_t s) {
 template <int R>
 static int launch_rb16_down(const ResblockArgs& a, hipStream_t s) {
     static PerDeviceOnce attr_once;
-    constexpr size_t smem = (size_t)Rb16Layout<32, 128>::total + 1024;
-    constexpr int OPT = (128 - 2 * R) / R + 1;
+    constexpr size_t smem = (size_t)Rb16Layout<32, 128>::total;
+    constexpr int OPT = (126 - 2 * R) / R + 1;
     auto kern = resblock16_kernel<32, 128, 1, false, R>;
     int dbg_req = 0;
     if (const char* e = getenv("WT_RB16_DBG")) dbg_req = atoi(e);
