@@ -38,7 +38,12 @@ if __name__ == "__main__":
         sys.exit(0)
     r = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     masks = [int(m) for m in sys.argv[2:]] or [0]
+    prev = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "wavtokenizer_amd", "libwavtok_hip_prev.so")
     for m in masks:                      # the mask is read once per process: one child per mask
         env = dict(os.environ, WT_RB16_DBG=str(m))
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", str(r)], env=env, capture_output=True, text=True)
         print("r=%d dbg=%2d: %s us" % (r, m, out.stdout.strip() or out.stderr.strip()[-300:]), flush=True)
+        if m == 0 and os.path.exists(prev):          # the same call on tools/build_prev.sh's library, same box
+            env["WAVTOK_HIP_LIB"] = prev
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", str(r)], env=env, capture_output=True, text=True)
+            print("r=%d prev  : %s us" % (r, out.stdout.strip() or out.stderr.strip()[-300:]), flush=True)

@@ -60,6 +60,21 @@ __device__ __forceinline__ float amax4(float m, float a, float b, float c, float
     return fmaxf(fmaxf(m, fabsf(c)), fabsf(d));
 }
 #endif
+// The split-f16 form of two values, packed: hi = f16(v) (round to nearest even), lo = f16((v - hi) * 2048).  v_cvt_pk_f16_f32
+// for the hi pair, then lo = fma(hi, -2048, v * 2048) on v_fma_mixlo/mixhi_f16, which read hi as f16 straight from the packed
+// register and round the fp32 result to f16 themselves: 2 instructions per element instead of 3 (no v_cvt_f32_f16 back,
+// no separate convert).  The fma is exact in fp32 (v - hi is representable, the scale a power of two), so the bits equal
+// those of (_Float16)((v - (float)hi) * 2048.f).
+__device__ __forceinline__ void split2_f16(float a, float b, unsigned& hi_pk, unsigned& lo_pk) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t ab = {a, b};
+    hi_pk = __builtin_bit_cast(unsigned, __builtin_convertvector(ab, f16x2_t));
+    const f32x2_t s = ab * 2048.f;
+    const float m = -2048.f;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lo_pk) : "v"(hi_pk), "s"(m), "v"(s[0]));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo_pk) : "v"(hi_pk), "s"(m), "v"(s[1]));
+}
 __device__ __forceinline__ void range_report(unsigned* status, float amax) {
     if (status && amax >= 65504.f) __hip_atomic_fetch_or(status, (unsigned)WT_STATUS_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

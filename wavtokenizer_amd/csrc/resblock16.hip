@@ -22,25 +22,27 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float rb16_elu(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
+// ELU(alpha = 1): e = exp(x) - 1 >= x everywhere, so the median of (x, e, 0) is x for x > 0 and e otherwise: one v_med3_f32
+// instead of a compare and a select
+__device__ __forceinline__ float rb16_elu(float x) { return __builtin_amdgcn_fmed3f(x, __expf(x) - 1.f, 0.f); }
 
 __device__ __forceinline__ void rb16_split8(const float* v, f16x8& hi, f16x8& lo, float& amax) {
     amax = amax4(amax4(amax, v[0], v[1], v[2], v[3]), v[4], v[5], v[6], v[7]);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 h, l;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const _Float16 h = (_Float16)v[i];
-        hi[i] = h;
-        lo[i] = (_Float16)((v[i] - (float)h) * 2048.f);
-    }
+    for (int i = 0; i < 4; ++i) { unsigned a, b; split2_f16(v[2 * i], v[2 * i + 1], a, b); h[i] = a; l[i] = b; }
+    hi = __builtin_bit_cast(f16x8, h);
+    lo = __builtin_bit_cast(f16x8, l);
 }
 __device__ __forceinline__ void rb16_split4(const f32x4 v, f16x4& hi, f16x4& lo, float& amax) {
     amax = amax4(amax, v[0], v[1], v[2], v[3]);
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 h, l;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const _Float16 h = (_Float16)v[i];
-        hi[i] = h;
-        lo[i] = (_Float16)((v[i] - (float)h) * 2048.f);
-    }
+    for (int i = 0; i < 2; ++i) { unsigned a, b; split2_f16(v[2 * i], v[2 * i + 1], a, b); h[i] = a; l[i] = b; }
+    hi = __builtin_bit_cast(f16x4, h);
+    lo = __builtin_bit_cast(f16x4, l);
 }
 
 // LDS images (bytes).  An activation row of CH channels is CH*4 bytes: per 32 channels a 128-byte group
@@ -65,7 +67,7 @@ struct RbRow {
 template <int C, int ROWS>
 struct Rb16Layout {
     static constexpr int H = C / 2;
-    static constexpr int N1 = H < 32 ? 32 : H;       // conv3 output rows padded to an MFMA tile
+    static constexpr int N1 = H < 16 ? 16 : H;       // conv3 output rows: 16 (one 16x16x32 tile) or a multiple of 32
     static constexpr int K1 = 3 * C, K2 = H + C;
     static constexpr int NX = ROWS + 2;
     static constexpr int off_xe = 0;                                 // elu(x), rows -1 .. ROWS
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
     // FOLD: the tile fill is one MFMA pass of 32 x-rows per wave, so the tile is ROWS x-rows INCLUDING the k=3 halo and
     // yields ROWS - 2 frames of y (the last two MFMA columns of conv3 read two zero rows and are dropped)
     constexpr int VALID = FOLD ? ROWS - 2 : ROWS;
-    constexpr int OPT = DOWN ? (VALID - DK) / DOWN + 1 : 0;          // output frames per tile
+    constexpr int OPT = DOWN ? (VALID - DK) / (DOWN ? DOWN : 1) + 1 : 0;          // output frames per tile
     constexpr int DMT = (OPT + 15) / 16;                             // 16-frame MFMA row tiles of the down conv
     using L = Rb16Layout<C, ROWS>;
     using XR = RbRow<C>;
@@ -173,9 +175,8 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
     constexpr int WAVN = ROWS + 8;                                   // waveform samples per tile (k=7 halo + k=3 halo)
     f32x4 px[FOLD ? 1 : ITEMS][2];
     float pw = 0.f;
-    auto prefetch = [&](long tile) {
-        const int b = (int)(tile / tiles_per_clip);
-        const int t0 = tile_t0((int)(tile - (long)b * tiles_per_clip));
+    auto prefetch = [&](int b, int ti) {
+        const int t0 = tile_t0(ti);
         if (FOLD) {
             if (tid < WAVN) {                                        // sample index t0 - 4 + tid, k=7 reflect
                 int p = t0 - 4 + tid;
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
         *reinterpret_cast<f16x8*>(xe + XR::off(r, c8, 0)) = hi;
         *reinterpret_cast<f16x8*>(xe + XR::off(r, c8, 1)) = lo;
     };
-    if ((long)blockIdx.x < n_tiles) prefetch(blockIdx.x);
+    if ((long)blockIdx.x < n_tiles) prefetch((int)(blockIdx.x / (unsigned)tiles_per_clip), (int)(blockIdx.x % (unsigned)tiles_per_clip));
     // Folded first conv (seanet.py:117: SConv1d(1 -> 32, k = 7)) as a split-f16 MFMA: x[ch][frame] = sum over k of
     // A[ch][k] B[k][frame] with k = 0 .. 6 the taps, k = 7 the bias against a constant 1, k = 8 .. 15 zero.  This lane's A
     // fragment (channel fl, k half fh) stays in registers.
@@ -262,9 +263,8 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
     const int dbg = DBG ? a.dbg : 0;                 // timing experiments only (WT_RB16_DBG): 1 no tile fill, 2 no MFMA, 4 no store, 8 no down-conv taps, 16 no ELU
     constexpr float LO_SCALE = 1.f / 2048.f;
 
+    int b = (int)(blockIdx.x / (unsigned)tiles_per_clip), ti = (int)(blockIdx.x % (unsigned)tiles_per_clip);
     for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int b = (int)(tile / tiles_per_clip);
-        const int ti = (int)(tile - (long)b * tiles_per_clip);
         const int t0 = tile_t0(ti);
         __syncthreads();                             // previous tile fully consumed (and weights landed)
         if (dbg & 1) { __syncthreads(); } else
@@ -295,15 +295,16 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
             }
             f16x8 bh, bl;
             rb16_split8(v, bh, bl, amax);
-            if (fh) { bh = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; bl = bh; }
+            // (the fh = 1 lanes hold the same samples against k = 8 .. 15, where A is zero)
             f32x16 xm, xc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { xm[i] = 0.f; xc[i] = 0.f; }
             xm = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0h, bh, xm, 0, 0, 0);
             xc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0l, bh, xc, 0, 0, 0);
             xc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0h, bl, xc, 0, 0, 0);
-            // lane: row r, channels 8 g + 4 fh .. + 3.  Raw split -> xr row r - 1 (row 0 has none: its lanes zero xr row ROWS - 1,
-            // which the invalid last MFMA column of the shortcut reads), elu split -> xe row r
+            // lane: row r, channels 8 g + 4 fh .. + 3.  Raw split -> xr row r - 1 (row 0 has none: its lanes fill xr row ROWS - 1,
+            // which only the dropped last MFMA column of the shortcut reads, so that it holds tile data, not stale bits),
+            // elu split -> xe row r
             const int xrow = r == 0 ? ROWS - 1 : r - 1;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
                 for (int i = 0; i < 4; ++i) {
                     const float x = xm[4 * g + i] + xc[4 * g + i] * LO_SCALE;
                     e4[i] = (DBG && (a.dbg & 16)) ? x : rb16_elu(x);
-                    x4[i] = r == 0 ? 0.f : x;
+                    x4[i] = x;
                 }
                 f16x4 hi, lo;
                 rb16_split4(x4, hi, lo, amax);
@@ -338,52 +339,102 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
             }
         }
         __syncthreads();
-        if (tile + gridDim.x < n_tiles) prefetch(tile + gridDim.x);
+        if (tile + gridDim.x < n_tiles) {
+            int nb = b, nti = ti + (int)gridDim.x;
+            while (nti >= tiles_per_clip) { nti -= tiles_per_clip; ++nb; }
+            prefetch(nb, nti);
+        }
 
         // ---- conv3 (transposed): h[n][frame] = sum over (tap, ci) W3[n][tap][ci] * elu(x)[frame + tap - 1][ci]
-        constexpr int TN1 = L::N1 / 32;
-        f32x16 a1m[TN1], a1c[TN1];
+        if constexpr (L::H == 16) {
+            // C = 32: the 16 hidden channels are exactly one v_mfma_f32_16x16x32_f16 row tile and a K step is one tap's 32 input
+            // channels (no zero-padded rows as with 32x32x16): lane (m16, q) holds A = W3[m16][tap][8 q ..], B = elu(x) of frame
+            // 16 nt + m16 + tap, channels 8 q .. 8 q + 7; D: frame m16, hidden channels 4 q .. 4 q + 3
+            static_assert(C == 32, "one K step per tap");
+            const int m16 = lane & 15, q = lane >> 4;
+            f32x4 hm[2], hc[2];
 #pragma unroll
-        for (int j = 0; j < TN1; ++j)
+            for (int nt = 0; nt < 2; ++nt) { hm[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; hc[nt] = hm[nt]; }
+            if (!(dbg & 2))
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { a1m[j][r] = 0.f; a1c[j][r] = 0.f; }
-        if (!(dbg & 2))
+            for (int tap = 0; tap < 3; ++tap) {
+                const f16x8 wh = *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, 2 * tap + (q >> 1), 0, m16, q & 1));
+                const f16x8 wl = *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, 2 * tap + (q >> 1), 1, m16, q & 1));
+                f16x8 bh[2], bl[2];
 #pragma unroll
-        for (int ks = 0; ks < L::K1 / 16; ++ks) {
-            const int tap = (ks * 16) / C, ci = (ks * 16) % C + 8 * fh;
-            const int xrow = row0 + fl + tap;                    // xe row index = frame + 1 + (tap - 1)
-            const f16x8 bh = *reinterpret_cast<const f16x8*>(xe + XR::off(xrow, ci, 0));
-            const f16x8 bl = *reinterpret_cast<const f16x8*>(xe + XR::off(xrow, ci, 1));
-#pragma unroll
-            for (int j = 0; j < TN1; ++j) {
-                const f16x8 wh = *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, ks, 0, j * 32 + fl, fh));
-                const f16x8 wl = *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, ks, 1, j * 32 + fl, fh));
-                a1m[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, a1m[j], 0, 0, 0);
-                a1c[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, a1c[j], 0, 0, 0);
-                a1c[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, a1c[j], 0, 0, 0);
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int xrow = row0 + 16 * nt + m16 + tap;
+                    bh[nt] = *reinterpret_cast<const f16x8*>(xe + XR::off(xrow, 8 * q, 0));
+                    bl[nt] = *reinterpret_cast<const f16x8*>(xe + XR::off(xrow, 8 * q, 1));
+                }
+                // issue order: no MFMA directly behind the one it depends on
+                hm[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh[0], hm[0], 0, 0, 0);
+                hc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh[0], hc[0], 0, 0, 0);
+                hm[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh[1], hm[1], 0, 0, 0);
+                hc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh[1], hc[1], 0, 0, 0);
+                hc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl[0], hc[0], 0, 0, 0);
+                hc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl[1], hc[1], 0, 0, 0);
             }
-        }
-        // elu(h + b3), split, into this wave's own rows of he.  D layout: lane -> frame fl, register r -> row
-        // n = 32 j + (r & 3) + 8 (r >> 2) + 4 fh
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bb + 4 * q);
 #pragma unroll
-        for (int j = 0; j < TN1; ++j)
+            for (int nt = 0; nt < 2; ++nt) {
+                f32x4 v;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = j * 32 + 8 * g + 4 * fh;
-                if (n < L::H) {
-                    f32x4 v;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        v[i] = a1m[j][4 * g + i] + a1c[j][4 * g + i] * LO_SCALE + bb[n + i];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (!(dbg & 16)) v[i] = rb16_elu(v[i]);
-                    f16x4 hi, lo;
-                    rb16_split4(v, hi, lo, amax);
-                    *reinterpret_cast<f16x4*>(he + HR::off(row0 + fl, n & ~7, 0) + (n & 7) * 2) = hi;
-                    *reinterpret_cast<f16x4*>(he + HR::off(row0 + fl, n & ~7, 1) + (n & 7) * 2) = lo;
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = hm[nt][i] + hc[nt][i] * LO_SCALE + b4[i];
+                    if (!(dbg & 16)) v[i] = rb16_elu(v[i]);
+                }
+                f16x4 hi, lo;
+                rb16_split4(v, hi, lo, amax);
+                const int n = 4 * q, frame = row0 + 16 * nt + m16;
+                *reinterpret_cast<f16x4*>(he + HR::off(frame, n & ~7, 0) + (n & 7) * 2) = hi;
+                *reinterpret_cast<f16x4*>(he + HR::off(frame, n & ~7, 1) + (n & 7) * 2) = lo;
+            }
+        } else {
+            constexpr int TN1 = L::N1 / 32;
+            f32x16 a1m[TN1], a1c[TN1];
+    #pragma unroll
+            for (int j = 0; j < TN1; ++j)
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) { a1m[j][r] = 0.f; a1c[j][r] = 0.f; }
+            if (!(dbg & 2))
+    #pragma unroll
+            for (int ks = 0; ks < L::K1 / 16; ++ks) {
+                const int tap = (ks * 16) / C, ci = (ks * 16) % C + 8 * fh;
+                const int xrow = row0 + fl + tap;                    // xe row index = frame + 1 + (tap - 1)
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(xe + XR::off(xrow, ci, 0));
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(xe + XR::off(xrow, ci, 1));
+    #pragma unroll
+                for (int j = 0; j < TN1; ++j) {
+                    const f16x8 wh = *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, ks, 0, j * 32 + fl, fh));
+                    const f16x8 wl = *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, ks, 1, j * 32 + fl, fh));
+                    a1m[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, a1m[j], 0, 0, 0);
+                    a1c[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, a1c[j], 0, 0, 0);
+                    a1c[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, a1c[j], 0, 0, 0);
                 }
             }
+            // elu(h + b3), split, into this wave's own rows of he.  D layout: lane -> frame fl, register r -> row
+            // n = 32 j + (r & 3) + 8 (r >> 2) + 4 fh
+    #pragma unroll
+            for (int j = 0; j < TN1; ++j)
+    #pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = j * 32 + 8 * g + 4 * fh;
+                    if (n < L::H) {
+                        f32x4 v;
+    #pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            v[i] = a1m[j][4 * g + i] + a1c[j][4 * g + i] * LO_SCALE + bb[n + i];
+    #pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (!(dbg & 16)) v[i] = rb16_elu(v[i]);
+                        f16x4 hi, lo;
+                        rb16_split4(v, hi, lo, amax);
+                        *reinterpret_cast<f16x4*>(he + HR::off(row0 + fl, n & ~7, 0) + (n & 7) * 2) = hi;
+                        *reinterpret_cast<f16x4*>(he + HR::off(row0 + fl, n & ~7, 1) + (n & 7) * 2) = lo;
+                    }
+                }
+        }
         // no barrier: a wave reads back only its own he rows, and a wave's LDS operations execute in order
 
         // ---- y[n][frame] = [W1 | Ws][n] . [elu(h) | x][frame] + (b1 + bs)
@@ -467,7 +518,7 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
                 const int o = 16 * mt + m16;
                 const int t_out = ti * OPT + o;
                 const bool valid = o < OPT && t_out < Tdown;
-                f32x4 dm = {0.f, 0.f, 0.f, 0.f}, dc = dm;
+                f32x4 dm = {0.f, 0.f, 0.f, 0.f}, dc = dm, dc2 = dm;     // two correction chains: no MFMA directly behind its producer
                 if (dbg & 8) {
                 } else if (inner) {
 #pragma unroll
@@ -478,7 +529,7 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
                         const f16x8 yl = *reinterpret_cast<const f16x8*>(src + (base ^ (((j % DOWN) * (8 / DOWN)) * 16) ^ 64));
                         dm = __builtin_amdgcn_mfma_f32_16x16x32_f16(wdh[DOWN ? j : 0], yh, dm, 0, 0, 0);
                         dc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wdl[DOWN ? j : 0], yh, dc, 0, 0, 0);
-                        dc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wdh[DOWN ? j : 0], yl, dc, 0, 0, 0);
+                        dc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wdh[DOWN ? j : 0], yl, dc2, 0, 0, 0);
                     }
                 } else {
 #pragma unroll
@@ -492,17 +543,19 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
                         const f16x8 yl = *reinterpret_cast<const f16x8*>(xr + xr_off(row, 8 * q, 1));
                         dm = __builtin_amdgcn_mfma_f32_16x16x32_f16(wdh[DOWN ? j : 0], yh, dm, 0, 0, 0);
                         dc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wdl[DOWN ? j : 0], yh, dc, 0, 0, 0);
-                        dc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wdh[DOWN ? j : 0], yl, dc, 0, 0, 0);
+                        dc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wdh[DOWN ? j : 0], yl, dc2, 0, 0, 0);
                     }
                 }
                 if (valid && !(dbg & 4)) {
                     f32x4 v;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = dm[i] + dc[i] * LO_SCALE + bd4[i];
+                    for (int i = 0; i < 4; ++i) v[i] = dm[i] + (dc[i] + dc2[i]) * LO_SCALE + bd4[i];
                     *reinterpret_cast<f32x4*>(a.y_down + ((long)b * Tdown + t_out) * 64 + 16 * wave + 4 * q) = v;
                 }
             }
         }
+        ti += (int)gridDim.x;
+        while (ti >= tiles_per_clip) { ti -= tiles_per_clip; ++b; }
     }
     range_report(a.status, fmaxf(amax, wmax));
 }
