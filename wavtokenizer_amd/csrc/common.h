@@ -75,6 +75,18 @@ __device__ __forceinline__ void split2_f16(float a, float b, unsigned& hi_pk, un
     asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lo_pk) : "v"(hi_pk), "s"(m), "v"(s[0]));
     asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo_pk) : "v"(hi_pk), "s"(m), "v"(s[1]));
 }
+typedef _Float16 wt_f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split4_f16(float a, float b, float c, float d, wt_f16x4& hi, wt_f16x4& lo) {
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    unsigned h0, l0, h1, l1;
+    split2_f16(a, b, h0, l0);
+    split2_f16(c, d, h1, l1);
+    hi = __builtin_bit_cast(wt_f16x4, (u32x2_t){h0, h1});
+    lo = __builtin_bit_cast(wt_f16x4, (u32x2_t){l0, l1});
+}
+// ELU(alpha = 1): e = exp(x) - 1 >= x everywhere, so the median of (x, e, 0) is x for x > 0 and e otherwise: one v_med3_f32
+// instead of a compare and a select
+__device__ __forceinline__ float elu_med3(float x) { return __builtin_amdgcn_fmed3f(x, __expf(x) - 1.f, 0.f); }
 __device__ __forceinline__ void range_report(unsigned* status, float amax) {
     if (status && amax >= 65504.f) __hip_atomic_fetch_or(status, (unsigned)WT_STATUS_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -34,7 +34,7 @@ __device__ __forceinline__ int xcd_remap_s(int orig, int nwg) {
     int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + idx;
 }
-__device__ __forceinline__ float elu_s(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
+__device__ __forceinline__ float elu_s(float x) { return elu_med3(x); }
 // erf to < 1 ulp (max abs error 6.3e-8 against float64 erf over [-6, 6], checked on the host), branch-free: the
 // two minimax pieces |a| <= 475/512 (odd polynomial) and beyond (1 - exp(polynomial)) are both evaluated and selected
 __device__ __forceinline__ float erf_s(float a) {
@@ -99,9 +99,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_s32_x4(float* row, int n, const f32x4 v, float& amax) {
     amax = amax4(amax, v.x, v.y, v.z, v.w);
     f16x4 hi, lo;
-    hi.x = (_Float16)v.x; hi.y = (_Float16)v.y; hi.z = (_Float16)v.z; hi.w = (_Float16)v.w;
-    lo.x = (_Float16)((v.x - (float)hi.x) * 2048.f); lo.y = (_Float16)((v.y - (float)hi.y) * 2048.f);
-    lo.z = (_Float16)((v.z - (float)hi.z) * 2048.f); lo.w = (_Float16)((v.w - (float)hi.w) * 2048.f);
+    split4_f16(v.x, v.y, v.z, v.w, hi, lo);
     _Float16* g = reinterpret_cast<_Float16*>(row) + ((n >> 5) * 64 + (n & 31));
     *reinterpret_cast<f16x4*>(g) = hi;
     *reinterpret_cast<f16x4*>(g + 32) = lo;
@@ -614,9 +612,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
                             } else {
                                 amax = amax4(amax, v.x, v.y, v.z, v.w);
                                 f16x4 hi, lo;
-                                hi.x = (_Float16)v.x; hi.y = (_Float16)v.y; hi.z = (_Float16)v.z; hi.w = (_Float16)v.w;
-                                lo.x = (_Float16)((v.x - (float)hi.x) * 2048.f); lo.y = (_Float16)((v.y - (float)hi.y) * 2048.f);
-                                lo.z = (_Float16)((v.z - (float)hi.z) * 2048.f); lo.w = (_Float16)((v.w - (float)hi.w) * 2048.f);
+                                split4_f16(v.x, v.y, v.z, v.w, hi, lo);
                                 *reinterpret_cast<f16x4*>(sc + rw * 128 + (((cw >> 3) ^ sww) * 16) + 2 * (cw & 7)) = hi;
                                 *reinterpret_cast<f16x4*>(sc + rw * 128 + (((4 + (cw >> 3)) ^ sww) * 16) + 2 * (cw & 7)) = lo;
                             }

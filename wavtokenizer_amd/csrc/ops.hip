@@ -25,9 +25,7 @@ __device__ __forceinline__ void store_s32_1(float* row_base, int e, float v, flo
 __device__ __forceinline__ void store_s32_4(float* row_base, int e, const f32x4 v, float& amax) {   // e % 4 == 0
     amax = amax4(amax, v.x, v.y, v.z, v.w);
     f16x4s hi, lo;
-    hi.x = (_Float16)v.x; hi.y = (_Float16)v.y; hi.z = (_Float16)v.z; hi.w = (_Float16)v.w;
-    lo.x = (_Float16)((v.x - (float)hi.x) * 2048.f); lo.y = (_Float16)((v.y - (float)hi.y) * 2048.f);
-    lo.z = (_Float16)((v.z - (float)hi.z) * 2048.f); lo.w = (_Float16)((v.w - (float)hi.w) * 2048.f);
+    split4_f16(v.x, v.y, v.z, v.w, hi, lo);
     _Float16* p = reinterpret_cast<_Float16*>(row_base) + ((e >> 5) * 64 + (e & 31));
     *reinterpret_cast<f16x4s*>(p) = hi;
     *reinterpret_cast<f16x4s*>(p + 32) = lo;

@@ -22,9 +22,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-// ELU(alpha = 1): e = exp(x) - 1 >= x everywhere, so the median of (x, e, 0) is x for x > 0 and e otherwise: one v_med3_f32
-// instead of a compare and a select
-__device__ __forceinline__ float rb16_elu(float x) { return __builtin_amdgcn_fmed3f(x, __expf(x) - 1.f, 0.f); }
+__device__ __forceinline__ float rb16_elu(float x) { return elu_med3(x); }
 
 __device__ __forceinline__ void rb16_split8(const float* v, f16x8& hi, f16x8& lo, float& amax) {
     amax = amax4(amax4(amax, v[0], v[1], v[2], v[3]), v[4], v[5], v[6], v[7]);
