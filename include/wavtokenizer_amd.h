@@ -237,7 +237,7 @@ int wt_resblock(const float* x, const float* wav, const float* e0_w, const float
                 const float* w1, const float* b1, const float* ws, const float* bs, float* y, int32_t B, int64_t T,
                 int32_t C, int32_t elu_out, int32_t out_s32, int32_t fp32_chain, void* stream);
 /* wt_resblock's shipped stage-1 form: first conv + resblock + ELU + the stage's strided conv (seanet.py:123-127) in one
- * launch.  wd [64][2r][32] (out, tap, in), y_down [B][T / r][64] fp32; r in {2, 4}, T % r == 0, T >= 1024. */
+ * launch.  wd [64][2r][32] (out, tap, in), y_down [B][ceil(T / r)][64] fp32; r in {2, 4}, T >= 1024. */
 int wt_resblock_down(const float* wav, const float* e0_w, const float* e0_b, const float* w3, const float* b3, const float* w1,
                      const float* b1, const float* ws, const float* bs, const float* wd, const float* bd, float* y_down,
                      int32_t B, int64_t T, int32_t r, void* stream);

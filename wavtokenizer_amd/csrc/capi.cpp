@@ -516,7 +516,7 @@ int wt_resblock(const float* x, const float* wav, const float* e0_w, const float
 }
 
 // The stage-1 kernel of the shipped encode plan: first conv + SEANetResnetBlock + ELU + the stage's down conv in one launch
-// (resblock16.hip, DOWN); wd [64][2r][32], y_down [B][T / r][64] fp32.
+// (resblock16.hip, DOWN); wd [64][2r][32], y_down [B][ceil(T / r)][64] fp32.
 int wt_resblock_down(const float* wav, const float* e0_w, const float* e0_b, const float* w3, const float* b3, const float* w1,
                      const float* b1, const float* ws, const float* bs, const float* wd, const float* bd, float* y_down,
                      int32_t B, int64_t T, int32_t r, void* stream) {
@@ -525,7 +525,7 @@ int wt_resblock_down(const float* wav, const float* e0_w, const float* e0_b, con
     }
     if (B < 1 || T < 1 || (long)B * T >= (long)INT_MAX) { set_error("wt_resblock_down: bad shape"); return WT_ERR_INVALID; }
     if (!resblock16_down_fusable(32, T, r, 2 * r)) {
-        set_error("wt_resblock_down: needs stride 2 or 4, T % stride == 0 and T >= 1024"); return WT_ERR_INVALID;
+        set_error("wt_resblock_down: needs stride 2 or 4 and T >= 1024"); return WT_ERR_INVALID;
     }
     ResblockArgs a{};
     a.wav = wav; a.e0_w = e0_w; a.e0_b = e0_b; a.W3 = w3; a.b3 = b3; a.W1 = w1; a.b1 = b1; a.Ws = ws; a.bs = bs;

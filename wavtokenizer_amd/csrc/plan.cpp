@@ -266,7 +266,7 @@ int build_encode(wt_plan* P) {
                                si + 1 < M->stages.size() && resblock_fusable(M->stages[si + 1].C) && st.down.cin == 32 &&
                                st.down.cout == 64 && resblock16_down_fusable(st.C, Tc, st.r, st.down.k);
         if (fuse_down) {
-            const long Td = Tc / st.r;
+            const long Td = sconv_args(st.down, B, Tc, st.r, 1).T_out;      // ceil(Tc / r)
             const int y = P->buf("enc." + std::to_string(idx + 2), (size_t)B * Td * st.down.cout);
             P->step({-1, y}, [=](const RunCtx& c) {
                 ResblockArgs a{};

@@ -159,9 +159,15 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
         bb[e] = e < L::N1 ? (e < L::H ? a.b3[e] : 0.f) : (a.b1[e - L::N1] + a.bs[e - L::N1]);
 
     const long xbs = a.x_bstride ? a.x_bstride : (long)a.T * C;
-    const int Tdown = DOWN ? a.T / (DOWN ? DOWN : 1) : 0;            // host: T % r == 0
+    const int Tdown = DOWN ? (a.T + DOWN - 1) / (DOWN ? DOWN : 1) : 0;   // conv.py:54-61: the last window is completed by extra (reflected) padding
     const int tiles_per_clip = DOWN ? (Tdown + OPT - 1) / (OPT ? OPT : 1) : (a.T + VALID - 1) / VALID;
-    auto tile_t0 = [&](int ti) { return DOWN ? ti * OPT * DOWN - DOWN / 2 : ti * VALID; };
+    // DOWN: a window that would run past the clip is shifted left to end at it, so that the frames the last outputs take
+    // their reflected taps from are inside it (host: T >= 1024 > VALID)
+    auto tile_t0 = [&](int ti) {
+        if (!DOWN) return ti * VALID;
+        const int nominal = ti * OPT * DOWN - DOWN / 2;
+        return nominal + VALID > a.T ? a.T - VALID : nominal;
+    };
     const long n_tiles = (long)a.B * tiles_per_clip;
     const int Tp1 = a.T > 1 ? a.T : 2;               // reflect pad 1 (k=3): conv.py:86-91
     const int Tp3 = a.T > 3 ? a.T : 4;               // reflect pad 3 (k=7)
@@ -510,7 +516,7 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
             // a tile whose taps all lie inside the clip reads frame o * r + j for output o, tap j: with the plane layout
             // that is a per-lane base (two of them: j < r, j >= r) XOR a constant, plus an immediate
             const int last_o = (ti * OPT + OPT <= Tdown ? ti * OPT + OPT : Tdown) - 1;
-            const bool inner = ti > 0 && last_o * DOWN - DOWN / 2 + DK - 1 < a.T;
+            const bool inner = ti > 0 && t0 == ti * OPT * DOWN - DOWN / 2 && last_o * DOWN - DOWN / 2 + DK - 1 < a.T;
 #pragma unroll 1                                                    // (unrolled, hipcc hoists every tap's fragment reads: registers)
             for (int mt = 0; mt < DMT; ++mt) {
                 const int o = 16 * mt + m16;
@@ -586,7 +592,7 @@ static int launch_rb16(const ResblockArgs& a, hipStream_t s) {
     return 0;
 }
 
-// stage 1 with the down conv fused in: wav [B][T] -> y_down [B][T / r][64] fp32 (r = a.R = 2 or 4)
+// stage 1 with the down conv fused in: wav [B][T] -> y_down [B][ceil(T / r)][64] fp32 (r = a.R = 2 or 4)
 template <int R>
 static int launch_rb16_down(const ResblockArgs& a, hipStream_t s) {
     static PerDeviceOnce attr_once;
@@ -603,7 +609,7 @@ static int launch_rb16_down(const ResblockArgs& a, hipStream_t s) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         return 0;
     })) return rc;
-    const long tiles = (long)a.B * ((a.T / R + OPT - 1) / OPT);
+    const long tiles = (long)a.B * (((a.T + R - 1) / R + OPT - 1) / OPT);
     const int per_cu = (int)(160 * 1024 / smem) < 4 ? (int)(160 * 1024 / smem) : 4;
     const long grid = tiles < 256L * per_cu ? tiles : 256L * per_cu;
     ResblockArgs b = a;
@@ -614,11 +620,11 @@ static int launch_rb16_down(const ResblockArgs& a, hipStream_t s) {
     return 0;
 }
 
-bool resblock16_down_fusable(int C, long T, int r, int k) { return C == 32 && (r == 2 || r == 4) && k == 2 * r && T % r == 0 && T >= 1024; }
+bool resblock16_down_fusable(int C, long T, int r, int k) { return C == 32 && (r == 2 || r == 4) && k == 2 * r && T >= 1024; }
 
 int launch_resblock16_down(const ResblockArgs& a, hipStream_t s) {
     if (!a.wav || !a.Wd || !a.bd || !a.y_down || !resblock16_down_fusable(a.C, a.T, a.R, 2 * a.R)) {
-        set_error("resblock16_down: needs the waveform, C = 32, stride 2 or 4 with k = 2 * stride, T % stride == 0, T >= 1024"); return -1;
+        set_error("resblock16_down: needs the waveform, C = 32, stride 2 or 4 with k = 2 * stride, T >= 1024"); return -1;
     }
     return a.R == 4 ? launch_rb16_down<4>(a, s) : launch_rb16_down<2>(a, s);
 }
