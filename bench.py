@@ -125,7 +125,7 @@ def pmc_traffic(arch_name, B, clip_seconds):
     with open(files[-1]) as f:
         kernels = json.load(f)["kernels"]
     for name, v in kernels.items():
-        if "gemm16s_kernel" in name and name.rstrip().endswith(", 2, 1>(wt::GemmArgs)"):     # EPI_BIAS_GELU, S32 out
+        if "gemm16s_kernel<128, 192, 4, 2, 3, 2, 1" in name:     # EPI_BIAS_GELU, S32 out (then the DBG and MFMA-shape parameters)
             return v["traffic_bytes_per_launch"]
     return None
 

@@ -266,3 +266,16 @@ def test_packed_image_header_is_validated_without_a_gpu():
     hdr[4:8] = np.frombuffer(np.int32(2).tobytes(), dtype=np.uint8)
     rc, msg = info(hdr)
     assert rc != 0 and "hash" in msg                   # zeroed architecture + zero hash: caught as a corrupt header
+
+
+def test_bench_finds_the_dominant_kernel_in_the_committed_pmc_summary():
+    """roofline.traffic comes from profiles/r*_pmc_traffic.json; a renamed kernel (new template parameter) must not turn it
+    into null unnoticed."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    t = bench.pmc_traffic("hop600", 64, 3)
+    assert t is not None and 101e6 < t < 400e6, t
