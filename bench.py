@@ -318,7 +318,7 @@ def main():
                        if world > 1 and not args.no_gather else "none"},
             "roofline": {"bound": "mfma",
                          "kernel": "wt::gemm16s_kernel<128,192,4,2,3,EPI_BIAS_GELU=2,OUT_S32=1> (ConvNeXt pwconv1 GEMM %dx%dx%d + GELU, "
-                                   "split-f16: 3 x v_mfma_f32_32x32x16_f16 per fp32-equivalent product)" % (Mrows, arch.intermediate_dim, arch.dim),
+                                   "split-f16: 3 x v_mfma_f32_16x16x32_f16 per fp32-equivalent product)" % (Mrows, arch.intermediate_dim, arch.dim),
                          "achieved": round(achieved, 2), "peak": round(PEAK_F16X3_TFLOPS, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F16X3_TFLOPS, 4), "traffic": pmc_traffic(args.arch, B, clip_s),
                          "peak_note": "algorithmic fp32-equivalent FLOP/s; peak = %.1f TF dense f16 MFMA / 3 MFMAs per product; the kernel "
