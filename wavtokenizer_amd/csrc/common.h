@@ -87,6 +87,18 @@ __device__ __forceinline__ void split4_f16(float a, float b, float c, float d, w
 // ELU(alpha = 1): e = exp(x) - 1 >= x everywhere, so the median of (x, e, 0) is x for x > 0 and e otherwise: one v_med3_f32
 // instead of a compare and a select
 __device__ __forceinline__ float elu_med3(float x) { return __builtin_amdgcn_fmed3f(x, __expf(x) - 1.f, 0.f); }
+// four at once, written on vectors so that the scale by log2(e) and the -1 become v_pk_mul_f32 / v_pk_add_f32
+typedef float wt_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ wt_f32x4 elu_med3_x4(wt_f32x4 x) {
+    const wt_f32x4 t = x * 1.44269504088896340736f;
+    wt_f32x4 e;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(t[i]);
+    e = e - 1.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_fmed3f(x[i], e[i], 0.f);
+    return e;
+}
 __device__ __forceinline__ void range_report(unsigned* status, float amax) {
     if (status && amax >= 65504.f) __hip_atomic_fetch_or(status, (unsigned)WT_STATUS_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -91,9 +91,13 @@ __device__ __forceinline__ int rb16_woff(int rows, int ks, int hl, int n, int h)
 // A tile is the 128-frame window [i*OPT*r - r/2, + 128) that OPT = (128 - 2r)/r + 1 consecutive output frames need
 // (31 for r = 4, 63 for r = 2: consecutive windows overlap by r frames, 3 % recomputed); wave w owns output channels
 // [16 w, 16 w + 16) with its 2r x 32 weights resident in registers as v_mfma_f32_16x16x32_f16 operands.
-template <int C, int ROWS, int FOLD, bool DBG = false, int DOWN = 0>
-__global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(const ResblockArgs a) {
+// FPW = frames per wave: 32 (one v_mfma_f32_32x32x16_f16 column block per wave, 4 waves) or 16 (C = 64: 8 waves, everything on
+// v_mfma_f32_16x16x32_f16).  The 64-channel tile + weights take 130 KB of LDS, i.e. one workgroup per CU: with 4 waves that is ONE
+// wave per SIMD and nothing overlaps its fill, MFMA and store phases; 8 waves of 16 frames give every SIMD a second wave.
+template <int C, int ROWS, int FOLD, bool DBG = false, int DOWN = 0, int FPW = 32>
+__global__ __launch_bounds__(ROWS / FPW * 64, DOWN ? 2 : 1) void resblock16_kernel(const ResblockArgs a) {
     static_assert(DOWN == 0 || (C == 32 && ROWS == 128 && FOLD == 1 && (DOWN == 2 || DOWN == 4)), "fused down conv: stage 1 only");
+    static_assert(FPW == 32 || (FPW == 16 && C == 64 && FOLD == 0 && DOWN == 0), "16 frames per wave: the plain 64-channel block");
     constexpr int DK = 2 * DOWN;                                     // down conv taps
     // FOLD: the tile fill is one MFMA pass of 32 x-rows per wave, so the tile is ROWS x-rows INCLUDING the k=3 halo and
     // yields ROWS - 2 frames of y (the last two MFMA columns of conv3 read two zero rows and are dropped)
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
     using L = Rb16Layout<C, ROWS>;
     using XR = RbRow<C>;
     using HR = RbRow<L::H>;
-    constexpr int NT = ROWS * 2;                     // one wave per 32 frames
+    constexpr int NT = ROWS / FPW * 64;              // one wave per FPW frames
     extern __shared__ __attribute__((aligned(256))) char smem16[];
     char* xe = smem16 + L::off_xe;
     char* xr = smem16 + L::off_xr;
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
     }
 
     const int fl = lane & 31, fh = lane >> 5;        // MFMA lane: (row or column fl, k half fh)
-    const int row0 = wave * 32;                      // this wave's frames inside the tile
+    const int row0 = wave * FPW;                     // this wave's frames inside the tile
     const int dbg = DBG ? a.dbg : 0;                 // timing experiments only (WT_RB16_DBG): 1 no tile fill, 2 no MFMA, 4 no store, 8 no down-conv taps, 16 no ELU
     constexpr float LO_SCALE = 1.f / 2048.f;
 
@@ -313,13 +317,10 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = 8 * g + 4 * fh;
-                f32x4 x4, e4;
+                f32x4 x4;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float x = xm[4 * g + i] + xc[4 * g + i] * LO_SCALE;
-                    e4[i] = (DBG && (a.dbg & 16)) ? x : rb16_elu(x);
-                    x4[i] = x;
-                }
+                for (int i = 0; i < 4; ++i) x4[i] = xm[4 * g + i] + xc[4 * g + i] * LO_SCALE;
+                const f32x4 e4 = (DBG && (a.dbg & 16)) ? x4 : elu_med3_x4(x4);
                 f16x4 hi, lo;
                 rb16_split4(x4, hi, lo, amax);
                 *reinterpret_cast<f16x4*>(xr + xr_off(xrow, n & ~7, 0) + (n & 7) * 2) = hi;
@@ -349,6 +350,104 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
             prefetch(nb, nti);
         }
 
+        if constexpr (FPW == 16) {
+            // ---- the 64-channel block, 16 frames per wave, on v_mfma_f32_16x16x32_f16: lane (m16, q) = (frame, k quarter);
+            // a K step is 32 channels of one operand row; D: frame m16, output rows 16 mt + 4 q .. + 3
+            static_assert(L::H == 32 && L::N1 == 32, "two 16-row tiles of hidden channels");
+            const int m16 = lane & 15, q = lane >> 4;
+            const int frame = row0 + m16;
+            f32x4 hm[2], hc[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) { hm[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; hc[mt] = hm[mt]; }
+            if (!(dbg & 2))
+#pragma unroll
+            for (int st = 0; st < 6; ++st) {                        // conv3: K = 3 taps x 64 channels, step = (tap, channel half)
+                const int tap = st >> 1, cb = (st & 1) * 32;
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(xe + XR::off(frame + tap, cb + 8 * q, 0));
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(xe + XR::off(frame + tap, cb + 8 * q, 1));
+                f16x8 wh[2], wl[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    wh[mt] = *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, 2 * st + (q >> 1), 0, 16 * mt + m16, q & 1));
+                    wl[mt] = *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, 2 * st + (q >> 1), 1, 16 * mt + m16, q & 1));
+                }
+                hm[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[0], bh, hm[0], 0, 0, 0);
+                hc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[0], bh, hc[0], 0, 0, 0);
+                hm[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[1], bh, hm[1], 0, 0, 0);
+                hc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[1], bh, hc[1], 0, 0, 0);
+                hc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[0], bl, hc[0], 0, 0, 0);
+                hc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[1], bl, hc[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {                        // elu(h + b3), split, into this wave's own rows of he
+                const int n = 16 * mt + 4 * q;
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bb + n);
+                f32x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = hm[mt][i] + hc[mt][i] * LO_SCALE + b4[i];
+                if (!(dbg & 16)) v = elu_med3_x4(v);
+                f16x4 hi, lo;
+                rb16_split4(v, hi, lo, amax);
+                *reinterpret_cast<f16x4*>(he + HR::off(frame, n & ~7, 0) + (n & 7) * 2) = hi;
+                *reinterpret_cast<f16x4*>(he + HR::off(frame, n & ~7, 1) + (n & 7) * 2) = lo;
+            }
+            // y = [W1 | Ws] . [elu(h) | x]: K = 32 + 64 = three steps; 64 output channels = four row tiles
+            f32x4 ym[4], yc[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) { ym[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; yc[mt] = ym[mt]; }
+            if (!(dbg & 2))
+#pragma unroll
+            for (int st = 0; st < 3; ++st) {
+                f16x8 bh, bl;
+                if (st == 0) {
+                    bh = *reinterpret_cast<const f16x8*>(he + HR::off(frame, 8 * q, 0));
+                    bl = *reinterpret_cast<const f16x8*>(he + HR::off(frame, 8 * q, 1));
+                } else {
+                    bh = *reinterpret_cast<const f16x8*>(xr + xr_off(frame, (st - 1) * 32 + 8 * q, 0));
+                    bl = *reinterpret_cast<const f16x8*>(xr + xr_off(frame, (st - 1) * 32 + 8 * q, 1));
+                }
+                f16x8 wh[4], wl[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    wh[mt] = *reinterpret_cast<const f16x8*>(w2 + rb16_woff(C, 2 * st + (q >> 1), 0, 16 * mt + m16, q & 1));
+                    wl[mt] = *reinterpret_cast<const f16x8*>(w2 + rb16_woff(C, 2 * st + (q >> 1), 1, 16 * mt + m16, q & 1));
+                }
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) ym[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mt], bh, ym[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) yc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[mt], bh, yc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) yc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mt], bl, yc[mt], 0, 0, 0);
+            }
+            // stage the wave's 16 frames in its own xr rows (the shortcut was their last reader), then full-line stores
+            char* stg = xr + row0 * XR::bytes;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int n = 16 * mt + 4 * q;
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bb + L::N1 + n);
+                f32x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = ym[mt][i] + yc[mt][i] * LO_SCALE + b4[i];
+                if (a.elu_out && !(dbg & 16)) v = elu_med3_x4(v);
+                if (a.out_s32) {
+                    f16x4 hi, lo;
+                    rb16_split4(v, hi, lo, amax);
+                    const int ch = (n >> 5) * 8 + ((n & 31) >> 3);
+                    *reinterpret_cast<f16x4*>(stg + m16 * XR::bytes + ((ch ^ XR::swz(m16)) * 16) + (n & 7) * 2) = hi;
+                    *reinterpret_cast<f16x4*>(stg + m16 * XR::bytes + (((ch + 4) ^ XR::swz(m16)) * 16) + (n & 7) * 2) = lo;
+                } else {
+                    *reinterpret_cast<f32x4*>(stg + m16 * XR::bytes + (((n >> 2) ^ XR::swz(m16)) * 16)) = v;
+                }
+            }
+            constexpr int LPR = XR::chunks, RPI = 64 / LPR;         // 16 lanes per 256-byte row, 4 rows per store instruction
+            const long tbase = (long)b * a.T + t0 + row0;
+#pragma unroll
+            for (int it = 0; it < FPW / RPI; ++it) {
+                const int r = it * RPI + lane / LPR, ch = lane % LPR;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * XR::bytes + ((ch ^ XR::swz(r)) * 16));
+                if (t0 + row0 + r < a.T && !(dbg & 4)) *reinterpret_cast<f32x4*>(a.y + (tbase + r) * C + ch * 4) = v;
+            }
+        } else {
         // ---- conv3 (transposed): h[n][frame] = sum over (tap, ci) W3[n][tap][ci] * elu(x)[frame + tap - 1][ci]
         if constexpr (L::H == 16) {
             // C = 32: the 16 hidden channels are exactly one v_mfma_f32_16x16x32_f16 row tile and a K step is one tap's 32 input
@@ -384,10 +483,8 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
             for (int nt = 0; nt < 2; ++nt) {
                 f32x4 v;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v[i] = hm[nt][i] + hc[nt][i] * LO_SCALE + b4[i];
-                    if (!(dbg & 16)) v[i] = rb16_elu(v[i]);
-                }
+                for (int i = 0; i < 4; ++i) v[i] = hm[nt][i] + hc[nt][i] * LO_SCALE + b4[i];
+                if (!(dbg & 16)) v = elu_med3_x4(v);
                 f16x4 hi, lo;
                 rb16_split4(v, hi, lo, amax);
                 const int n = 4 * q, frame = row0 + 16 * nt + m16;
@@ -429,9 +526,7 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
     #pragma unroll
                         for (int i = 0; i < 4; ++i)
                             v[i] = a1m[j][4 * g + i] + a1c[j][4 * g + i] * LO_SCALE + bb[n + i];
-    #pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (!(dbg & 16)) v[i] = rb16_elu(v[i]);
+                        if (!(dbg & 16)) v = elu_med3_x4(v);
                         f16x4 hi, lo;
                         rb16_split4(v, hi, lo, amax);
                         *reinterpret_cast<f16x4*>(he + HR::off(row0 + fl, n & ~7, 0) + (n & 7) * 2) = hi;
@@ -481,10 +576,8 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
                     const int n = j * 32 + 8 * g + 4 * fh;
                     f32x4 v;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        v[i] = a2m[j][4 * g + i] + a2c[j][4 * g + i] * LO_SCALE + bb[L::N1 + n + i];
-                        if ((DOWN || a.elu_out) && !(dbg & 16)) v[i] = rb16_elu(v[i]);
-                    }
+                    for (int i = 0; i < 4; ++i) v[i] = a2m[j][4 * g + i] + a2c[j][4 * g + i] * LO_SCALE + bb[L::N1 + n + i];
+                    if ((DOWN || a.elu_out) && !(dbg & 16)) v = elu_med3_x4(v);
                     if (DOWN || a.out_s32) {                        // S32: chunk (n/32)*8 + n%32/8 holds hi, + 4 holds lo
                         f16x4 hi, lo;
                         rb16_split4(v, hi, lo, amax);
@@ -558,25 +651,26 @@ __global__ __launch_bounds__(ROWS * 2, DOWN ? 2 : 1) void resblock16_kernel(cons
                 }
             }
         }
+        }   // FPW == 32
         ti += (int)gridDim.x;
         while (ti >= tiles_per_clip) { ti -= tiles_per_clip; ++b; }
     }
     range_report(a.status, fmaxf(amax, wmax));
 }
 
-template <int C, int ROWS, int FOLD>
+template <int C, int ROWS, int FOLD, int FPW = 32>
 static int launch_rb16(const ResblockArgs& a, hipStream_t s) {
     static PerDeviceOnce attr_once;
     constexpr size_t smem = (size_t)Rb16Layout<C, ROWS>::total;
     static_assert(smem <= 160 * 1024, "LDS budget");
-    auto kern = resblock16_kernel<C, ROWS, FOLD>;
+    auto kern = resblock16_kernel<C, ROWS, FOLD, false, 0, FPW>;
     int dbg_req = 0;
     if (const char* e = getenv("WT_RB16_DBG")) dbg_req = atoi(e);
-    if (dbg_req) kern = resblock16_kernel<C, ROWS, FOLD, true>;
+    if (dbg_req) kern = resblock16_kernel<C, ROWS, FOLD, true, 0, FPW>;
     if (int rc = attr_once.run([&]() -> int {
-        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock16_kernel<C, ROWS, FOLD>),
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock16_kernel<C, ROWS, FOLD, false, 0, FPW>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock16_kernel<C, ROWS, FOLD, true>),
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock16_kernel<C, ROWS, FOLD, true, 0, FPW>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         return 0;
     })) return rc;
@@ -587,7 +681,7 @@ static int launch_rb16(const ResblockArgs& a, hipStream_t s) {
     ResblockArgs b = a;
     b.dbg = dbg_req;
     if (!b.status) b.status = g_launch.status;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(ROWS * 2), smem, s, b);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(ROWS / FPW * 64), smem, s, b);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -635,7 +729,10 @@ int launch_resblock16(const ResblockArgs& a, hipStream_t s) {
         set_error("resblock16: x must be 16-byte aligned"); return -1;
     }
     if (a.C == 32) return a.wav ? launch_rb16<32, 128, 1>(a, s) : launch_rb16<32, 128, 0>(a, s);
-    if (a.C == 64) return launch_rb16<64, 128, 0>(a, s);
+    if (a.C == 64) {
+        static const bool fpw32 = [] { const char* e = getenv("WT_RB16_FPW"); return e && atoi(e) == 32; }();      // A/B timing
+        return fpw32 ? launch_rb16<64, 128, 0, 32>(a, s) : launch_rb16<64, 128, 0, 16>(a, s);
+    }
     set_error("resblock16: fused kernel exists for C = 32 and 64");
     return -1;
 }
