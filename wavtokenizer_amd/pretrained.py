@@ -100,8 +100,13 @@ class EncodecFeatures(_Holder):
     def infer(self, audio: torch.Tensor, bandwidth_id: torch.Tensor):
         _ = self.bandwidths[self._root()._bandwidth_index(bandwidth_id)] if bandwidth_id is not None else None
         feats, codes, _emb = self._root()._run_encode(audio, want_emb=False)
-        commit_loss = torch.zeros((), device=audio.device)
-        return feats, codes, commit_loss
+        # the third element of the reference's tuple (feature_extractors.py:141) is a zero scalar in eval mode; one cached
+        # tensor per device instead of a fill kernel per call
+        z = getattr(self, "_zero_loss", None)
+        if z is None or z.device != audio.device:
+            z = torch.zeros((), device=audio.device)
+            object.__setattr__(self, "_zero_loss", z)
+        return feats, codes, z
 
 
 class VocosBackbone(_Holder):
