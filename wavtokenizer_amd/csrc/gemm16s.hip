@@ -801,6 +801,14 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
     int G = (256 * per_cu / a.nz) & ~7;
     const char* np = getenv("WT_GEMM16S_NONPERSISTENT");
     if (G < 8 || ntiles <= G || a.K / SBK < NSTAGE + 1 || (np && np[0] == '1')) G = ntiles;
+    else {
+        // the same number of rounds with the fewest workgroups (720 tiles: 240 x 3 instead of 208 x 3 + 48 x 2): the idle
+        // CUs' power goes to the clock of the busy ones
+        static const bool bal = [] { const char* e = getenv("WT_GEMM16S_BALANCE"); return !e || e[0] != '0'; }();
+        const int rounds = (ntiles + G - 1) / G;
+        const int g2 = (((ntiles + rounds - 1) / rounds) + 7) & ~7;
+        if (bal && g2 < G) G = g2;
+    }
     GemmArgs b = a;
     {   // per-wave bias (+ gamma) cache: WN floats each, filled by DMA at the top of every output tile
         constexpr bool pcache = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ELU || EPI == EPI_BIAS_RES ||
