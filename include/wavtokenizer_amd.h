@@ -66,7 +66,8 @@ typedef struct {
     int32_t adanorm_num_embeddings;  /* 4 */
     int32_t n_fft;                   /* 2400 / 1280 */
     int32_t hop_length;              /* 600 / 320 */
-    int32_t padding_same;            /* 1 = "same" (the only mode the YAMLs select) */
+    int32_t padding_same;            /* ISTFT padding (spectral_ops.py:33-47): 1 = "same" (every YAML; audio = L * hop samples), 0 = "center"
+                                        (torch.istft(center=True): (L - 1) * hop samples per clip, L >= 2) */
 } wt_arch;
 
 /* One named fp32 host array of a checkpoint `state_dict` (keys: SURVEY.md Appendix A). */

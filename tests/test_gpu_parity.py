@@ -318,6 +318,35 @@ def test_b8_fixture_codes(gpu_model):
         assert rel_l2(out[:, :256], g["wav_out_head"]) < 5 * WAV_REL_TOL
 
 
+def test_istft_center_padding():
+    """ISTFTHead with padding="center" (spectral_ops.py:43-45: torch.istft(center=True); no YAML selects it): decode of the
+    reference's features against the reference's captured waveform, (L - 1) * hop samples per clip; one frame is refused."""
+    import dataclasses
+    import os
+    from wavtokenizer_amd import WavTokenizer, NAMED_ARCHS
+    from tests.util import GOLDEN
+    from tests import parity_log
+    arch = dataclasses.replace(NAMED_ARCHS["hop600"], padding="center")
+    m = WavTokenizer.from_arch(arch)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict("hop600").items()}, strict=False)
+    m = m.eval().to("cuda")
+    g = np.load(os.path.join(GOLDEN, "hop600_center.npz"))
+    for tag in ("b2_t24000", "b1_t1300"):
+        feats = torch.from_numpy(g[f"{tag}/features"]).cuda()
+        want = g[f"{tag}/wav_out"]
+        got = m.decode(feats, bandwidth_id=BW).cpu().numpy()
+        assert got.shape == want.shape, (got.shape, want.shape)
+        err = rel_l2(got, want)
+        parity_log.record(f"istft_center[{tag}]", wav_rel_l2=err)
+        assert err < WAV_REL_TOL, (tag, err)
+    # round trip through the class: the same length rule
+    wav = torch.from_numpy(g["b2_t24000/wav_in"]).cuda()
+    f, c = m.encode_infer(wav, bandwidth_id=BW)
+    assert m.decode(f, bandwidth_id=BW).shape == (2, (f.shape[2] - 1) * arch.hop_length)
+    with pytest.raises(Exception):
+        m.decode(f[:, :, :1].contiguous(), bandwidth_id=BW)
+
+
 def test_errors_like_the_reference(gpu_model):
     name, m, _sd = gpu_model
     feats = torch.zeros(1, 512, 4, device="cuda")

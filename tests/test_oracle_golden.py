@@ -119,3 +119,21 @@ def test_seanet_decoder_fixture():
         out = orc.seanet_decoder(torch.from_numpy(g["z"]))
     assert tuple(out.shape) == g["wav_out"].shape == (2, 1, 20 * 600)
     assert rel_l2(out.numpy(), g["wav_out"]) < FLOAT_TOL
+
+
+def test_istft_center_padding_fixture():
+    """ISTFT padding="center" (spectral_ops.py:43-45, torch.istft(center=True)): the oracle against outputs captured from the
+    reference with its ISTFT switched to that mode (tests/golden/make_golden_center.py); (L - 1) * hop samples per clip."""
+    import dataclasses
+    import os
+    from tests.util import GOLDEN
+    arch = dataclasses.replace(NAMED_ARCHS["hop600"], padding="center")
+    orc = OracleWavTokenizer(arch, synth_state_dict("hop600"))
+    g = np.load(os.path.join(GOLDEN, "hop600_center.npz"))
+    for tag in ("b2_t24000", "b1_t1300"):
+        feats = torch.from_numpy(g[f"{tag}/features"])
+        want = g[f"{tag}/wav_out"]
+        with torch.inference_mode():
+            got = orc.decode(feats, torch.tensor([0])).numpy()
+        assert got.shape == want.shape == (feats.shape[0], (feats.shape[2] - 1) * arch.hop_length)
+        assert np.array_equal(got, want), tag

@@ -18,7 +18,6 @@ const char* wt_version(void) { return "wavtokenizer_amd 0.1 (gfx950, split-f16 M
 int wt_model_create(const wt_arch* arch, const wt_tensor* tensors, int32_t n_tensors, int32_t device, wt_model** out) {
     if (!arch || !tensors || !out) { set_error("wt_model_create: null argument"); return WT_ERR_INVALID; }
     if (arch->n_ratios < 1 || arch->n_ratios > 8) { set_error("n_ratios out of range"); return WT_ERR_INVALID; }
-    if (!arch->padding_same) { set_error("only ISTFT padding='same' is implemented (the mode every reference YAML selects)"); return WT_ERR_INVALID; }
     if (arch->num_quantizers != 1) { set_error("only num_quantizers=1 is implemented (vq.py:137 forces n_q=1 at inference)"); return WT_ERR_INVALID; }
     if (arch->input_channels != 512) { set_error("input_channels must be 512 (SEANet dimension)"); return WT_ERR_INVALID; }
     if (arch->dim % 256 || arch->intermediate_dim % 32) { set_error("dim must be a multiple of 256, intermediate_dim of 32"); return WT_ERR_INVALID; }
@@ -142,12 +141,14 @@ int wt_plan_create(const wt_model* m, int32_t kind, int32_t B, int64_t len, int3
         rc = build_encode(P.get());
     } else if (kind == WT_PLAN_DECODE) {
         P->L = len; P->T = len * m->hop;
+        if (!m->arch.padding_same && len < 2) { set_error("ISTFT padding='center' needs at least two frames"); (void)hipHostFree(P->status_host); return WT_ERR_INVALID; }
         rc = build_decode(P.get());
     } else if (kind == WT_PLAN_SEANET_DECODER) {
         P->L = len; P->T = len * m->hop;
         rc = build_seanet_decoder(P.get());
     } else if (kind == WT_PLAN_HEAD) {
         P->L = len; P->T = len * m->hop;
+        if (!m->arch.padding_same && len < 2) { set_error("ISTFT padding='center' needs at least two frames"); (void)hipHostFree(P->status_host); return WT_ERR_INVALID; }
         rc = build_head(P.get());
     } else if (kind == WT_PLAN_UNIT_LSTM) {
         P->L = len; P->T = len * m->hop;

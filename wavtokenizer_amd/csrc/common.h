@@ -210,8 +210,8 @@ enum RowNormMode : int { RN_DWCONV = 0, RN_PLAIN = 1, RN_AFFINE_IN = 2 };
 int launch_rownorm(int mode, const float* x, float* y, int B, int L, int C, const float* dw_w /*[7][C]*/,
                    const float* dw_b, const float* in_scale, const float* in_shift, const float* out_scale,
                    const float* out_shift, float eps, hipStream_t s, int out_s32 = 0);
-int launch_istft_ola(const float* parts /*[4][M][Kq]*/, const float* win, const float* wsq, float* out, int B, int L,
-                     int n_fft, int hop, int Kq, hipStream_t s);
+int launch_istft_ola(const float* parts, const float* win, const float* wsq, float* out, int B, int L, int n_fft, int hop,
+                     int Kq, int center, hipStream_t s);
 int launch_softmax(float* S, int rows, int L, int ld, hipStream_t s, float* P_s32 = nullptr);
 int launch_row_sumsq(const float* x, float* out, long rows, int D, hipStream_t s);
 int launch_vq_finalize(const float* pval, const int* pidx, int nparts, const float* embed, int64_t* codes,

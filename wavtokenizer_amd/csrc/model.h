@@ -272,5 +272,9 @@ int build_unit_lstm(wt_plan* P);
 // the control block and the closing guard step that every plan kind gets (plan.cpp)
 void plan_begin(wt_plan* P);
 void plan_end(wt_plan* P);
+// samples per clip that the ISTFT head writes for L frames: "same" L * hop, "center" (torch.istft(center=True)) (L - 1) * hop
+inline long wave_samples(const wt_model* M, long L) {
+    return M->arch.padding_same ? L * (long)M->arch.hop_length : (L - 1) * (long)M->arch.hop_length;
+}
 
 }  // namespace wt

@@ -768,15 +768,16 @@ int launch_softmax(float* S, int rows, int L, int ld, hipStream_t s, float* P_s3
 }
 
 // ------------------------------------------------------------------------------- ISTFT tail
-// ISTFT.forward 'same' (decoder/spectral_ops.py:56-73) after the four quarter transforms
+// ISTFT.forward (decoder/spectral_ops.py:33-75) after the four quarter transforms
 // Ce, Co, Se, So [frame][0..N/4]: rebuild x_t[n] with the two radix-2 butterflies, multiply by the
 // window, overlap-add the n_fft/hop frames that cover an output sample (ascending n, like fold),
-// trim (n_fft-hop)/2 and divide by the window-square envelope.  One thread per output sample.
+// trim and divide by the window-square envelope.  One thread per output sample.
+// "same" (:46, 56-73): trim (n_fft - hop) / 2 at both ends, L * hop samples.  "center" (:43-45, torch.istft(center=True)):
+// trim n_fft / 2 at both ends, (L - 1) * hop samples; the same overlap-add and the same envelope otherwise.
 __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict__ parts, const float* __restrict__ win,
                                                         const float* __restrict__ wsq, float* __restrict__ out,
-                                                        long total, long Mrows, int L, int N, int hop, int Kq) {
-    const int pad = (N - hop) / 2, R = N / hop, Q = N / 4, Nh = N / 2;
-    const long Tout = (long)hop * L;
+                                                        long total, long Mrows, int L, int N, int hop, int Kq, int pad, long Tout) {
+    const int R = N / hop, Q = N / 4, Nh = N / 2;
     const float* Ce = parts;
     const float* Co = parts + Mrows * Kq;
     const float* Se = parts + 2 * Mrows * Kq;
@@ -806,11 +807,14 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
 }
 
 int launch_istft_ola(const float* parts, const float* win, const float* wsq, float* out, int B, int L, int n_fft, int hop,
-                     int Kq, hipStream_t s) {
-    const long total = (long)B * L * hop;
+                     int Kq, int center, hipStream_t s) {
+    const int pad = center ? n_fft / 2 : (n_fft - hop) / 2;
+    const long Tout = center ? (long)hop * (L - 1) : (long)hop * L;
+    const long total = (long)B * Tout;
+    if (total <= 0) return 0;
     int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipLaunchKernelGGL(istft_ola_kernel, dim3(blocks), dim3(256), 0, s, parts, win, wsq, out, total, (long)B * L, L, n_fft,
-                       hop, Kq);
+                       hop, Kq, pad, Tout);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -386,7 +386,7 @@ static void plan_head(wt_plan* P, int xo, bool s32) {
         return gemm_auto(P, a, PRO_NONE, EPI_BIAS, c.stream);
     }, 1, "head.istft");
     P->step({parts}, [=](const RunCtx& c) {
-        return launch_istft_ola(P->ptr(c, parts), M->win, M->wsq, c.out_f, B, L, ar.n_fft, hop, Kq, c.stream);
+        return launch_istft_ola(P->ptr(c, parts), M->win, M->wsq, c.out_f, B, L, ar.n_fft, hop, Kq, ar.padding_same ? 0 : 1, c.stream);
     }, 1, "head.ola");
 }
 
@@ -764,8 +764,9 @@ void plan_end(wt_plan* P) {
         long nc = 0, n0 = 0, n1 = 0;
         float* f1 = c.aux;
         if (kind == WT_PLAN_ENCODE) { codes = c.codes; nc = B * L; n0 = B * 512 * L; n1 = n0; }
-        else if (kind == WT_PLAN_DECODE) { n0 = B * L * hop; n1 = B * L * D; }
+        else if (kind == WT_PLAN_DECODE) { n0 = B * wave_samples(M, L); n1 = B * L * D; }
         else if (kind == WT_PLAN_UNIT_LSTM) { n0 = B * L * 512; f1 = nullptr; }
+        else if (kind == WT_PLAN_HEAD) { n0 = B * wave_samples(M, L); f1 = nullptr; }
         else { n0 = B * L * hop; f1 = nullptr; }
         return launch_plan_guard(reinterpret_cast<const unsigned*>(P->ptr(c, ctl)), P->status_dev, codes, nc, c.out_f, n0, f1, n1,
                                  nullptr, 0, c.stream);

@@ -519,6 +519,10 @@ class WavTokenizer(nn.Module):
     def arch(self) -> ArchConfig:
         return self._arch
 
+    def _wave_len(self, L: int) -> int:
+        """Samples per clip the ISTFT head returns for L frames (spectral_ops.py:43-47): 'same' L * hop, 'center' (L - 1) * hop."""
+        return L * self._arch.hop_length if self._arch.padding == "same" else (L - 1) * self._arch.hop_length
+
     @property
     def hop_length(self) -> int:
         return self._arch.hop
@@ -603,11 +607,11 @@ class WavTokenizer(nn.Module):
             if flags & _capi.WT_PLAN_FLAG_GRAPH:
                 io = self._engine.staging(_capi.WT_PLAN_DECODE, B, L, flags, lambda: {
                     "in": torch.empty((B, self._arch.input_channels, L), dtype=torch.float32, device=dev),
-                    "wav": torch.empty((B, L * self._arch.hop_length), dtype=torch.float32, device=dev)})
+                    "wav": torch.empty((B, self._wave_len(L)), dtype=torch.float32, device=dev)})
                 io["in"].copy_(features)
                 check(lib.wt_decode(plan, _ptr(io["in"]), bw, _ptr(io["wav"]), _ptr(None), _ptr(ws), _stream_ptr(dev)), "wt_decode")
                 return io["wav"].clone(), None
-            wav = torch.empty((B, L * self._arch.hop_length), dtype=torch.float32, device=dev)
+            wav = torch.empty((B, self._wave_len(L)), dtype=torch.float32, device=dev)
             bb = torch.empty((B, L, self._arch.dim), dtype=torch.float32, device=dev) if want_backbone else None
             check(lib.wt_decode(plan, _ptr(features), bw, _ptr(wav), _ptr(bb), _ptr(ws), _stream_ptr(dev)), "wt_decode")
             return wav, bb
@@ -621,7 +625,7 @@ class WavTokenizer(nn.Module):
         B, L, _ = x.shape
 
         def launch(plan, ws):
-            wav = torch.empty((B, L * self._arch.hop_length), dtype=torch.float32, device=dev)
+            wav = torch.empty((B, self._wave_len(L)), dtype=torch.float32, device=dev)
             check(lib.wt_head(plan, _ptr(x), _ptr(wav), _ptr(ws), _stream_ptr(dev)), "wt_head")
             return wav
 
