@@ -1,14 +1,40 @@
 """Time the stage-1 kernel (first conv + resblock + down conv, resblock16.hip) alone at the benchmark shape, optionally
 under the WT_RB16_DBG ablation masks (1 no tile fill, 2 no resblock MFMAs, 4 no stores, 8 no down-conv taps, 16 no ELU).
 
-    python tools/rb16_bench.py [r] [dbg masks ...]
+    python tools/rb16_bench.py [r] [dbg masks ...]        r = 4 / 2: stage 1 (hop-600 / hop-320); r = 0: the stage-2 resblock
 """
 import os
 import subprocess
 import sys
 
 
+def run_stage2(iters=20):
+    """the 64-channel resblock of encoder stage 2 (wt_resblock: 18000 frames x 64 clips, S32(elu) out)"""
+    import torch
+    from wavtokenizer_amd._capi import lib, check
+    B, T, C = 64, 18000, 64
+    g = torch.Generator().manual_seed(0)
+    rnd = lambda *s: (torch.randn(*s, generator=g) * 0.1).cuda()
+    x = rnd(B, T, C)
+    ws = [rnd(C // 2, 3, C), rnd(C // 2), rnd(C, C // 2), rnd(C), rnd(C, C), rnd(C)]
+    y = torch.empty(B, T, C, device="cuda")
+    p = lambda t: t.data_ptr()
+    call = lambda: check(lib.wt_resblock(p(x), None, None, None, *[p(w) for w in ws], p(y), B, T, C, 1, 1, 0, None), "wt_resblock")
+    for _ in range(3):
+        call()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
 def run(r, iters=20):
+    if r == 0:
+        return run_stage2(iters)
     import torch
     from wavtokenizer_amd._capi import lib, check
     B, T = 64, 72000
