@@ -730,7 +730,9 @@ int launch_resblock16(const ResblockArgs& a, hipStream_t s) {
     }
     if (a.C == 32) return a.wav ? launch_rb16<32, 128, 1>(a, s) : launch_rb16<32, 128, 0>(a, s);
     if (a.C == 64) {
-        static const bool fpw32 = [] { const char* e = getenv("WT_RB16_FPW"); return e && atoi(e) == 32; }();      // A/B timing
+        // A/B timing: WT_RB16_FPW=32 is the 4-wave form.  (Tried: 48-row tiles of 3 waves, 75 KB, i.e. two independent
+        // workgroups per CU: 252 us against 223 for the 8-wave form and 268 for the 4-wave form, kernel alone, one box.)
+        static const bool fpw32 = [] { const char* e = getenv("WT_RB16_FPW"); return e && atoi(e) == 32; }();
         return fpw32 ? launch_rb16<64, 128, 0, 32>(a, s) : launch_rb16<64, 128, 0, 16>(a, s);
     }
     set_error("resblock16: fused kernel exists for C = 32 and 64");
