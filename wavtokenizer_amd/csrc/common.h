@@ -142,6 +142,11 @@ struct GemmArgs {
     int T_in = 0, T_out = 0;     // rows per clip in / out;  M = nclips * T_out
     int Cin = 0, taps = 1, stride = 1, dil = 1, pad_left = 0, pad_mode = PAD_ZERO;
     int Tp = 0;           // reflect: effective length max(T_in, max_pad + 1) (conv.py:86-91)
+    // gemm16s, plain row-major operands only (taps = 1, stride 1, no padding): K columns [K1, K) come from a second S32
+    // tensor A2 with its own strides ([x | elu(h)] of a resblock's shortcut + conv1 in one contraction)
+    const float* A2 = nullptr;
+    long a2_bstride = 0, a2_rstride = 0;
+    int K1 = 0;
     // W
     const float* W = nullptr;
     long w_rstride = 0;

@@ -163,6 +163,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
 
     // S32 arrays are addressed in bytes = 4 x the fp32 element offset
     const char* Ag = reinterpret_cast<const char*>(p.A) + (long)z * p.zA * 4;
+    const char* Ag2 = reinterpret_cast<const char*>(p.A2);          // second K source (nz = 1: host)
     const char* Wg = reinterpret_cast<const char*>(p.W_hi) + (long)z * p.zW * 4;
     const long w_span = (long)p.N * p.w_rstride * 4;
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
@@ -205,6 +206,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
                     ok = (pos >= 0) && (pos < p.T_in);
                 }
                 if (ok) off = (unsigned)(((long)(b - clip0) * p.a_bstride + (long)pos * p.a_rstride) * 4);
+                // second source (taps = 1, stride 1, no padding: pos = t)
+                if (p.A2) s_rowoff[2 * tab_sz + par * BM + r] = (unsigned)(((long)(b - clip0) * p.a2_bstride + (long)t * p.a2_rstride) * 4);
+            } else if (p.A2) {
+                s_rowoff[2 * tab_sz + par * BM + r] = OOB;
             }
             tab[e] = off;
         }
@@ -227,8 +232,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
         const int q = BM / 8 + wave + NW * j;
         w_chunk[j] = (unsigned)(((lane & 7) ^ (((q & 1) << 2) | (lane >> 4))) * 16);
     }
-    unsigned a_voff[NPA], w_voff[NPB];
-    __amdgpu_buffer_rsrc_t rsA;
+    unsigned a_voff[NPA], a2_voff[NPA], w_voff[NPB];
+    __amdgpu_buffer_rsrc_t rsA, rsA2;
     int l_vb = blockIdx.x, l_par = 0, tapL = 0, ciL = 0, kL = 0;
     unsigned l_mask = 0;
     auto set_tap = [&](int tap) {
@@ -246,6 +251,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
         const long a_span = ((long)(nclips - clip0 - 1) * p.a_bstride + (long)p.T_in * p.a_rstride) * 4;
         rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Ablk), 0,
                                                 (int)(a_span < 0x7fffffffL ? a_span : 0x7fffffffL), 0x00020000);
+        if (p.A2) {
+            const long a2_span = ((long)(nclips - clip0 - 1) * p.a2_bstride + (long)p.T_in * p.a2_rstride) * 4;
+            rsA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Ag2 + (long)clip0 * p.a2_bstride * 4), 0,
+                                                     (int)(a2_span < 0x7fffffffL ? a2_span : 0x7fffffffL), 0x00020000);
+            const unsigned* tab2 = s_rowoff + 2 * tab_sz + par * BM;
+#pragma unroll
+            for (int i = 0; i < NPA; ++i) a2_voff[i] = tab2[a_row[i]] + a_chunk[i];
+        }
 #pragma unroll
         for (int j = 0; j < NPB; ++j) {
             const int n = bn * BN + (wave + NW * j) * 8 + prow;
@@ -256,6 +269,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(cons
     auto load_tile = [&](int stage) {
         const unsigned kadvA = (unsigned)ciL * 4u, kadvW = (unsigned)kL * 4u;
         char* sbase = smem_s + stage * STG + wave * 1024;
+        if (p.A2 && kL >= p.K1) {                                    // wave-uniform: this K tile comes from the second source
+            const unsigned kadv2 = (unsigned)(kL - p.K1) * 4u;
+#pragma unroll
+            for (int i = 0; i < NPA; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr_t)(sbase + NW * i * 1024), 16,
+                                                         (int)((a2_voff[i] | l_mask) + kadv2), 0, 0, 0);
+        } else
 #pragma unroll
         for (int i = 0; i < NPA; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(sbase + NW * i * 1024), 16,
@@ -755,7 +775,7 @@ template <int BM, int BN, int WMs, int WNs, int NSTAGE, int EPI, int OUT>
 static int launch16s_one(const GemmArgs& a, hipStream_t s) {
     static PerDeviceOnce attr_once;
     constexpr size_t stage_bytes = (size_t)NSTAGE * (BM + BN) * 128;
-    size_t smem = stage_bytes + 2ull * a.taps * BM * sizeof(unsigned);
+    size_t smem = stage_bytes + 2ull * a.taps * BM * sizeof(unsigned) + (a.A2 ? 2ull * BM * sizeof(unsigned) : 0);
     constexpr size_t smem_cap = 160 * 1024;
     constexpr size_t smem_want = stage_bytes + 2ull * 32 * BM * sizeof(unsigned) + (size_t)WMs * WNs * 4096 + 8192 + 256;
     constexpr size_t smem_max = smem_want < smem_cap ? smem_want : smem_cap;
@@ -905,6 +925,15 @@ int launch_gemm16s(const GemmArgs& a_in, int epi, int out, hipStream_t s) {
         }
     }
     if (c.pad_mode == PAD_REFLECT && c.Tp < c.T_in) { set_error("gemm16s: reflect Tp < T_in"); return -1; }
+    if (c.A2) {
+        const long clips_per_tile = 256 / c.T_out + 2;
+        if (c.taps != 1 || c.stride != 1 || c.pad_left != 0 || c.nz != 1 || c.T_in != c.T_out || c.K1 <= 0 || c.K1 >= c.K || (c.K1 % SBK) ||
+            (c.a2_rstride % 32) || (c.a2_bstride % 32) || (reinterpret_cast<uintptr_t>(c.A2) & 127) ||
+            (clips_per_tile * c.a2_bstride + (long)c.T_in * c.a2_rstride) * 4 >= 0x40000000L) {
+            set_error("gemm16s: a second K source needs a plain row-major problem (taps 1, stride 1, no padding) and K1 in multiples of 32");
+            return -1;
+        }
+    }
     GemmArgs a = a_in;
     a.group_m = (a.N + 191) / 192 > 8 ? 8 : 1;
     if (const char* e = getenv("WT_GEMM16S_GM")) a.group_m = atoi(e) > 0 ? atoi(e) : a.group_m;      // sweeps (tools/gemm16s_bench.py)

@@ -35,6 +35,7 @@ struct LstmW {
 };
 struct ResStage {
     ConvW c3, c1, sc, down;
+    ConvW cat;             // unfused stages (C >= 128): [Ws | W1] [C][C + C/2] and bs + b1, shortcut + conv1 as one contraction
     int C = 0, r = 0;
 };
 struct PosRes {
@@ -50,6 +51,7 @@ struct SeaDecStage {
     float* tr_b = nullptr;
     int cin = 0, cout = 0, k = 0, r = 0;
     ConvW c3, c1, sc;
+    ConvW cat;             // as ResStage::cat
 };
 
 }  // namespace wt

@@ -200,17 +200,32 @@ static int plan_lstm(wt_plan* P, const LstmW& w, int B, int L, int H, int xin, c
 // Unfused SEANetResnetBlock with every operand pre-split: x arrives as S32(x) (shortcut) and S32(elu(x)) (conv3),
 // the hidden activation and the output are written as S32(elu(.)); returns the output buffer
 static int plan_resblock_s32(wt_plan* P, const ConvW& c3, const ConvW& c1, const ConvW& sc, int B, long T, int x_raw,
-                             int x_elu, const std::string& name, long x_off = 0, long x_bstride = 0) {
+                             int x_elu, const std::string& name, long x_off = 0, long x_bstride = 0, const ConvW* cat = nullptr) {
     const int C = sc.cout;
     const int h = P->buf(name + ".h", (size_t)B * T * (C / 2), BUF_S32 | BUF_ELU);
-    const int y = P->buf(name + ".sc", (size_t)B * T * C);
-    const int o = P->buf(name, (size_t)B * T * C, BUF_S32 | BUF_ELU);
     GemmArgs a3 = sconv_args(c3, B, T, 1, 1);
     P->step({x_elu, h}, [=](const RunCtx& c) {
         GemmArgs a = a3; a.A = P->ptr(c, x_elu) + x_off; a.C = P->ptr(c, h);
         if (x_bstride) a.a_bstride = x_bstride;
         return gemm_s32(P, a, EPI_BIAS_ELU, OUT_S32, c.stream);
     });
+    static const bool cat_env = [] { const char* e = getenv("WT_RESBLOCK_CAT"); return !e || e[0] != '0'; }();      // A/B timing
+    if (cat && cat->w && cat_env && P->model->s32.count(cat->w)) {
+        // shortcut + conv1 as one GEMM over K = [x (C) | elu(h) (C/2)] (GemmArgs::A2): the fp32 shortcut tensor is neither
+        // written nor read back, and the output goes through the staged full-line epilogue
+        const int o = P->buf(name, (size_t)B * T * C, BUF_S32 | BUF_ELU);
+        GemmArgs ac = sconv_args(sc, B, T, 1, 1);
+        ac.W = cat->w; ac.w_rstride = cat->cin; ac.bias = cat->b; ac.K = cat->cin; ac.Cin = cat->cin;
+        ac.K1 = C; ac.a2_bstride = T * (C / 2); ac.a2_rstride = C / 2;
+        P->step({x_raw, h, o}, [=](const RunCtx& c) {
+            GemmArgs a = ac; a.A = P->ptr(c, x_raw) + x_off; a.A2 = P->ptr(c, h); a.C = P->ptr(c, o);
+            if (x_bstride) a.a_bstride = x_bstride;
+            return gemm_s32(P, a, EPI_BIAS_ELU, OUT_S32, c.stream);
+        });
+        return o;
+    }
+    const int y = P->buf(name + ".sc", (size_t)B * T * C);
+    const int o = P->buf(name, (size_t)B * T * C, BUF_S32 | BUF_ELU);
     GemmArgs as = sconv_args(sc, B, T, 1, 1);
     P->step({x_raw, y}, [=](const RunCtx& c) {
         GemmArgs a = as; a.A = P->ptr(c, x_raw) + x_off; a.C = P->ptr(c, y);
@@ -285,7 +300,7 @@ int build_encode(wt_plan* P) {
                               (idx == 1 && fold_e0) ? M : nullptr, 0, 0, ws32);
             x_is_s32 = ws32;
         } else if (ws32 && x_raw >= 0) {
-            x = plan_resblock_s32(P, st.c3, st.c1, st.sc, B, Tc, x_raw, x_elu, "enc." + std::to_string(idx));
+            x = plan_resblock_s32(P, st.c3, st.c1, st.sc, B, Tc, x_raw, x_elu, "enc." + std::to_string(idx), 0, 0, &st.cat);
             x_is_s32 = true;
         } else {
             x = plan_resblock(P, st.c3, st.c1, st.sc, B, Tc, x, "enc." + std::to_string(idx), fuse_elu, nullptr);
@@ -671,7 +686,7 @@ static int build_seanet_decoder_s32(wt_plan* P) {
         if (fused)
             x = plan_resblock(P, st.c3, st.c1, st.sc, B, To, y, "sdec." + std::to_string(di + 2), true, nullptr, y_off, y_bs, !last);
         else
-            x = plan_resblock_s32(P, st.c3, st.c1, st.sc, B, To, y, y2, "sdec." + std::to_string(di + 2), y_off, y_bs);
+            x = plan_resblock_s32(P, st.c3, st.c1, st.sc, B, To, y, y2, "sdec." + std::to_string(di + 2), y_off, y_bs, &st.cat);
         Tc = To; di += 3;
     }
     const int xin = x;

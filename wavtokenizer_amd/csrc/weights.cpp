@@ -154,6 +154,27 @@ static int load_lstm(wt_model* M, TensorMap& tm, const std::string& prefix, int 
     return upload(M, b1, &out->b1);
 }
 
+// SEANetResnetBlock tail (seanet.py:62-63): shortcut(x) + conv1(elu(h)) = [Ws | W1] . [x | elu(h)] + (bs + b1): both are 1x1
+// convs, so the unfused stages run them as ONE GEMM whose K columns come from two tensors (gemm16s, GemmArgs::A2)
+static int build_cat(wt_model* M, const ConvW& sc, const ConvW& c1, ConvW* cat) {
+    if (sc.k != 1 || c1.k != 1 || sc.cout != c1.cout) return 0;
+    const int C = sc.cout, K1 = sc.cin, K2 = c1.cin;
+    std::vector<float> ws((size_t)C * K1), w1((size_t)C * K2), bs(C), b1(C), w((size_t)C * (K1 + K2)), b(C);
+    WT_HIP_CHECK(hipMemcpy(ws.data(), sc.w, ws.size() * sizeof(float), hipMemcpyDeviceToHost));
+    WT_HIP_CHECK(hipMemcpy(w1.data(), c1.w, w1.size() * sizeof(float), hipMemcpyDeviceToHost));
+    WT_HIP_CHECK(hipMemcpy(bs.data(), sc.b, bs.size() * sizeof(float), hipMemcpyDeviceToHost));
+    WT_HIP_CHECK(hipMemcpy(b1.data(), c1.b, b1.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int n = 0; n < C; ++n) {
+        std::memcpy(&w[(size_t)n * (K1 + K2)], &ws[(size_t)n * K1], K1 * sizeof(float));
+        std::memcpy(&w[(size_t)n * (K1 + K2) + K1], &w1[(size_t)n * K2], K2 * sizeof(float));
+        b[n] = bs[n] + b1[n];
+    }
+    if (int rc = upload(M, w, &cat->w)) return rc;
+    if (int rc = upload(M, b, &cat->b)) return rc;
+    cat->cout = C; cat->cin = K1 + K2; cat->k = 1;
+    return 0;
+}
+
 static const char* ENC = "feature_extractor.encodec.encoder.model.";
 static const char* DEC = "feature_extractor.encodec.decoder.model.";
 static const char* VQK = "feature_extractor.encodec.quantizer.vq.layers.0._codebook.";
@@ -184,6 +205,7 @@ int build_model(wt_model* M, TensorMap& tm) {
         if (int rc = load_wn_conv(M, tm, p + ".block.3.conv.conv", st.C, st.C / 2, 1, &st.c1)) return rc;
         if (int rc = load_wn_conv(M, tm, p + ".shortcut.conv.conv", st.C, st.C, 1, &st.sc)) return rc;
         if (int rc = load_wn_conv(M, tm, std::string(ENC) + std::to_string(idx + 2) + ".conv.conv", 2 * st.C, st.C, 2 * r, &st.down)) return rc;
+        if (!resblock_fusable(st.C)) if (int rc = build_cat(M, st.sc, st.c1, &st.cat)) return rc;
         M->stages.push_back(st);
         idx += 3; mult *= 2;
     }
@@ -371,6 +393,7 @@ int build_model(wt_model* M, TensorMap& tm) {
             if (int rc = load_wn_conv(M, tm, rp + ".block.1.conv.conv", h / 2, h, 3, &st.c3)) return rc;
             if (int rc = load_wn_conv(M, tm, rp + ".block.3.conv.conv", h, h / 2, 1, &st.c1)) return rc;
             if (int rc = load_wn_conv(M, tm, rp + ".shortcut.conv.conv", h, h, 1, &st.sc)) return rc;
+            if (!resblock_fusable(h)) if (int rc = build_cat(M, st.sc, st.c1, &st.cat)) return rc;
             M->sd_stages.push_back(st);
             di += 3; m2 /= 2;
         }
@@ -473,6 +496,7 @@ int build_splits(wt_model* M) {
         if (int rc = conv32(st.c3)) return rc;
         if (int rc = conv32(st.c1)) return rc;
         if (int rc = conv32(st.sc)) return rc;
+        if (st.cat.w) if (int rc = conv32(st.cat)) return rc;
     }
     if (int rc = add_s32(M, M->enc_lstm.Wih0, 4L * M->H * M->H)) return rc;
     if (int rc = conv32(M->enc_final)) return rc;
@@ -500,6 +524,7 @@ int build_splits(wt_model* M) {
             if (int rc = conv32sd(st.sc)) return rc;
             if (int rc = conv32sd(st.c3)) return rc;
             if (int rc = conv32sd(st.c1)) return rc;
+            if (st.cat.w) if (int rc = conv32sd(st.cat)) return rc;
         }
     }
     for (const ResStage& st : M->stages) {
@@ -546,7 +571,7 @@ int build_splits(wt_model* M) {
 // header (magic, version, the wt_arch and a hash of it) and the model struct with every pointer written as
 // (allocation index).  Loading it is allocate + upload + fix up pointers: nothing is folded, packed or split again.
 static constexpr uint32_t PACK_MAGIC = 0x4b505457u;     // "WTPK"
-static constexpr int32_t PACK_VERSION = 2;
+static constexpr int32_t PACK_VERSION = 3;
 
 static uint64_t arch_hash_of(const wt_arch& a) {        // FNV-1a over the architecture struct and the layout version
     uint64_t h = 1469598103934665603ull;
@@ -596,7 +621,7 @@ static void archive_model(Archive& ar, wt_model* M) {
     for (int& r : M->enc_ratios) ar.pod(r);
     ar.ptr(M->e0_w); ar.ptr(M->e0_b); ar.pod(M->e0_k); ar.pod(M->e0_c);
     n = (int32_t)M->stages.size(); ar.pod(n); M->stages.resize(n);
-    for (ResStage& st : M->stages) { ar.conv(st.c3); ar.conv(st.c1); ar.conv(st.sc); ar.conv(st.down); ar.pod(st.C); ar.pod(st.r); }
+    for (ResStage& st : M->stages) { ar.conv(st.c3); ar.conv(st.c1); ar.conv(st.sc); ar.conv(st.down); ar.conv(st.cat); ar.pod(st.C); ar.pod(st.r); }
     ar.lstm(M->enc_lstm); ar.conv(M->enc_final); ar.ptr(M->embed); ar.ptr(M->ee);
     ar.conv(M->bb_embed);
     for (PosRes& r : M->res) { ar.ptr(r.n1w); ar.ptr(r.n1b); ar.ptr(r.n2w); ar.ptr(r.n2b); ar.conv(r.c1); ar.conv(r.c2); }
@@ -611,7 +636,7 @@ static void archive_model(Archive& ar, wt_model* M) {
     n = (int32_t)M->sd_stages.size(); ar.pod(n); M->sd_stages.resize(n);
     for (SeaDecStage& st : M->sd_stages) {
         ar.ptr(st.tr_w); ar.ptr(st.tr_wp); ar.ptr(st.tr_b); ar.pod(st.cin); ar.pod(st.cout); ar.pod(st.k); ar.pod(st.r);
-        ar.conv(st.c3); ar.conv(st.c1); ar.conv(st.sc);
+        ar.conv(st.c3); ar.conv(st.c1); ar.conv(st.sc); ar.conv(st.cat);
     }
     ar.ptr(M->sd_last_w); ar.ptr(M->sd_last_b);
     // the maps keyed by the fp32 weight pointer
