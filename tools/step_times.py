@@ -1,7 +1,7 @@
 """Per-step GPU time of the encode and decode plans at the benchmark shape (wt_plan_set_timing: HIP events around every
 launch whose step name contains the filter), one filter at a time, 10 round trips each.
 
-    python tools/step_times.py [out.md]
+    python tools/step_times.py [out.md] [clips] [samples]
 """
 import collections
 import ctypes
@@ -11,7 +11,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def main(out):
+def main(out, B=64, T=72000):
     import torch
     from wavtokenizer_amd import WavTokenizer, ARCH_HOP600, synth, _capi
     lib = _capi.lib
@@ -19,7 +19,8 @@ def main(out):
     m = WavTokenizer.from_arch(ARCH_HOP600)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     m = m.eval().to("cuda")
-    wav = torch.from_numpy(synth.make_clips(64, 72000, seed=2000)).cuda()
+    wav = torch.from_numpy(synth.make_clips(B, T, seed=2000)).cuda()
+    m.set_graph_max_clips(0)                               # time the launches themselves, not a graph replay
     bw = torch.tensor([0])
 
     def trip():
@@ -58,7 +59,7 @@ def main(out):
             per_call[name] = ms
         for name in sorted(count, key=names.index):
             rows.append((("encode" if key[0] == 0 else "decode"), name, count[name], 1e3 * per_call[name] / count[name], per_call[name]))
-    lines = ["# Per-step GPU time, hop-600, 64 x 3 s (HIP events around each launch; tools/step_times.py)", "",
+    lines = ["# Per-step GPU time, hop-600, %d x %.1f s (HIP events around each launch; tools/step_times.py)" % (B, T / 24000), "",
              "| plan | step | launches per call | us per launch | ms per call |", "|---|---|---|---|---|"]
     for plan, name, cnt, us, ms in rows:
         lines.append(f"| {plan} | `{name}` | {cnt} | {us:.1f} | {ms:.3f} |")
@@ -73,4 +74,4 @@ def main(out):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else None)
+    main(sys.argv[1] if len(sys.argv) > 1 else None, *(int(a) for a in sys.argv[2:4]))
