@@ -176,13 +176,15 @@ int wt_codes_to_features(const wt_model* m, const int64_t* codes, int32_t K, int
 /* Replaces: WavTokenizer.decode (decoder/pretrained.py:192-207): VocosBackbone.forward
  * (decoder/models.py:223-235) + ISTFTHead.forward (decoder/heads.py:42-67) + ISTFT.forward
  * (decoder/spectral_ops.py:33-75).
- *   features [B][512][L] fp32, bandwidth_id in [0, adanorm_num_embeddings), wav_out [B][L*hop].
+ *   features [B][512][L] fp32, bandwidth_id in [0, adanorm_num_embeddings), wav_out [B][L*hop] (padding "same";
+ *   "center": [B][(L-1)*hop], L >= 2).
  *   backbone_out optional [B][L][dim] fp32 (may be NULL). */
 int wt_decode(const wt_plan* p, const float* features, int32_t bandwidth_id, float* wav_out,
               float* backbone_out, void* workspace, void* stream);
 
 /* Replaces: ISTFTHead.forward (decoder/heads.py:42-67) + ISTFT.forward (decoder/spectral_ops.py:33-75) on its own,
- * reached by callers as model.head(x).  x [B][L][dim] fp32 (the backbone output), wav_out [B][L*hop]. */
+ * reached by callers as model.head(x).  x [B][L][dim] fp32 (the backbone output), wav_out [B][L*hop] ("center":
+ * [B][(L-1)*hop]). */
 int wt_head(const wt_plan* p, const float* x, float* wav_out, void* workspace, void* stream);
 
 /* Replaces: SEANetDecoder.forward (encoder/modules/seanet.py:236-238), reached by callers as
