@@ -2,15 +2,17 @@
 //
 //   y = shortcut(x) + conv1(elu(conv3(elu(x))))
 //
-// Same fusion as resblock.hip (x tile with its k=3 halo in LDS, optional first encoder conv folded into the tile
-// fill, conv1 frame-local, weights resident in LDS, persistent workgroups), but every contraction runs as
-// split-f16 (x = hi + lo * 2^-11, three v_mfma_f32_32x32x16_f16 per 16-deep step, main + correction accumulator:
-// gemm16.hip) instead of v_mfma_f32_32x32x2_f32: 27 MFMA x 32 cycles per 32 frames at C = 32 where the fp32 pipe
-// needs 72 x 64.  The split is done ONCE per element when the tile is filled (ELU too, not once per tap), the LDS
-// images hold rows of [hi | lo] f16 with XOR-swizzled 16-byte chunks so every ds_read_b128 fragment read is
-// conflict-free, and the weights are the MFMA's A operand: the accumulator comes out with the frame on the lane and
-// 4-channel runs in the registers, so the epilogue stores 16 bytes (fp32) or 8 + 8 bytes (S32, for the split-f16
-// down conv that follows) per lane.
+// Same fusion as resblock.hip (x tile with its k=3 halo in LDS, conv1 frame-local, weights resident in LDS, persistent
+// workgroups), but every contraction runs as split-f16 (x = hi + lo * 2^-11, three f16 MFMAs per K step, main + correction
+// accumulator: gemm16.hip) instead of v_mfma_f32_32x32x2_f32.  The split is done ONCE per element when the tile is filled
+// (ELU too, not once per tap), the LDS images hold rows of [hi | lo] f16 with XOR-swizzled 16-byte chunks so every
+// ds_read_b128 fragment read is conflict-free, and the weights are the MFMA's A operand: the accumulator comes out with the
+// frame on the lane and 4-channel runs in the registers, so the epilogue stores 16 bytes (fp32) or 8 + 8 bytes (S32) per lane.
+// Three forms (template arguments below):
+//   C = 32, FOLD: the first encoder conv (k7, 1 -> 32) is the tile fill, itself an MFMA pass over the waveform;
+//   C = 32, FOLD, DOWN = r: ... and ELU + the stage's strided conv run on the tile while it is in LDS: encoder stage 1 in one
+//       kernel (the shipped plan; wt_resblock_down);
+//   C = 64, FPW = 16: the plain block on 8 waves of 16 frames (encoder stage 2, SEANetDecoder).
 #include "common.h"
 
 #include <stdlib.h>
@@ -88,8 +90,9 @@ __device__ __forceinline__ int rb16_woff(int rows, int ks, int hl, int n, int h)
 // DOWN = r > 0 (C = 32 with the folded first conv only): the stage's down conv — ELU, SConv1d(32 -> 64, k = 2r, stride r,
 // reflect; seanet.py:123-127) — is computed from the tile's output while it is still in LDS, and only ITS output
 // (64 channels at 1/r of the frame rate) goes to HBM: the 590 MB of stage-1 activations are neither written nor read back.
-// A tile is the 128-frame window [i*OPT*r - r/2, + 128) that OPT = (128 - 2r)/r + 1 consecutive output frames need
-// (31 for r = 4, 63 for r = 2: consecutive windows overlap by r frames, 3 % recomputed); wave w owns output channels
+// A tile is the 126-frame window [i*OPT*r - r/2, + 126) that OPT = (126 - 2r)/r + 1 consecutive output frames need
+// (30 for r = 4, 62 for r = 2: consecutive windows overlap, 5 % recomputed; the last window of a clip is shifted to end at the
+// clip, so lengths that are no multiple of r work too); wave w owns output channels
 // [16 w, 16 w + 16) with its 2r x 32 weights resident in registers as v_mfma_f32_16x16x32_f16 operands.
 // FPW = frames per wave: 32 (one v_mfma_f32_32x32x16_f16 column block per wave, 4 waves) or 16 (C = 64: 8 waves, everything on
 // v_mfma_f32_16x16x32_f16).  The 64-channel tile + weights take 130 KB of LDS, i.e. one workgroup per CU: with 4 waves that is ONE
