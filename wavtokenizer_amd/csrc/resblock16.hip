@@ -77,7 +77,7 @@ struct Rb16Layout {
     static constexpr int off_w2 = off_w3 + (K1 / 16) * 2 * N1 * 32;  // [K2/16][hi, lo][C rows][32 B]
     static constexpr int off_b = off_w2 + (K2 / 16) * 2 * C * 32;    // b3[N1], b12[C] fp32
     static constexpr int off_wav = off_b + (N1 + C) * 4;             // folded first conv: ROWS + 8 samples
-    static constexpr int total = off_wav + (ROWS + 8) * 4;
+    static constexpr int total = off_wav + 2 * (ROWS + 8) * 4;       // two windows: the next tile's is written before the barrier that ends this one
 };
 
 // weight image: 16-deep k-step ks, part hl, row n: 32 bytes = k 16 ks .. +15 as two 16-byte chunks (k half h),
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(ROWS / FPW * 64, DOWN ? 2 : 1) void resblock16_kern
     char* w3 = smem16 + L::off_w3;
     char* w2 = smem16 + L::off_w2;
     float* bb = reinterpret_cast<float*>(smem16 + L::off_b);
-    float* wtile = reinterpret_cast<float*>(smem16 + L::off_wav);
+    float* wtile0 = reinterpret_cast<float*>(smem16 + L::off_wav);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float amax = 0.f, wmax = 0.f;        // largest activation / weight magnitude converted to the split-f16 form
     // Byte offset in xr of the 16-byte chunk `chunk` (0 .. C/4 - 1: hi chunks, then lo, per 32 channels) of frame row r.
@@ -275,15 +275,21 @@ __global__ __launch_bounds__(ROWS / FPW * 64, DOWN ? 2 : 1) void resblock16_kern
     constexpr float LO_SCALE = 1.f / 2048.f;
 
     int b = (int)(blockIdx.x / (unsigned)tiles_per_clip), ti = (int)(blockIdx.x % (unsigned)tiles_per_clip);
-    for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    int wpar = 0;
+    for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, wpar ^= 1) {
         const int t0 = tile_t0(ti);
-        __syncthreads();                             // previous tile fully consumed (and weights landed)
+        // FOLD: this tile's waveform window goes into the buffer that the tile before the previous one used (its readers
+        // passed the barrier after that tile's fill long ago), so ONE barrier covers "previous tile fully consumed", "weights
+        // landed" and "window visible": 424 -> 404 us (a barrier costs this kernel about 20 us).  Tried on top: no top barrier
+        // at all for DOWN (x_raw / staged y alternating between two LDS buffers, the next window written before the barrier in
+        // front of the down conv): 420 us — the waves drift apart and wait longer at the two barriers that remain.
+        float* wtile = wtile0 + wpar * (ROWS + 8);
+        if (FOLD && !(dbg & 1) && tid < ROWS + 8) wtile[tid] = pw;
+        __syncthreads();
         if (dbg & 1) { __syncthreads(); } else
         if (FOLD) {
             // first encoder conv from the staged samples: xe row r = frame t0 - 1 + r = b + sum_j w[j] * wavpad[frame + j - 3],
             // wtile[i] = wavpad[t0 - 4 + i].  Wave w produces rows 32 w .. 32 w + 31: B fragment = the lane's 7 samples + 1.
-            if (tid < WAVN) wtile[tid] = pw;
-            __syncthreads();
             const bool direct = (t0 - 4 >= 0) && (t0 + ROWS + 4 <= a.T);      // no reflected sample or frame in the window
             const int r = row0 + fl;
             float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
