@@ -143,43 +143,6 @@ def make_model(arch_name, dev):
     return model, arch, sd, time.perf_counter() - t0
 
 
-class Runner:
-    """encode_infer + decode steps of one (model, batch) with the end-of-step exchange of the sharded mode."""
-
-    def __init__(self, model, wav, bw, dist, world, rank, gather, backend):
-        self.model, self.wav, self.bw = model, wav, bw
-        self.dist, self.world, self.rank, self.gather, self.backend = dist, world, rank, gather and world > 1, backend
-        self.prev = None            # (codes, waveform) of the previous step, not yet exchanged
-
-    def _issue(self):
-        from wavtokenizer_amd.sharding import gather_async
-        codes, out = self.prev
-        self.prev = None
-        if self.backend == "gloo":                               # rehearsal only: through host memory
-            codes, out = codes.cpu(), out.cpu()
-        return gather_async(codes, out, self.dist, self.world, self.rank, dst=0)
-
-    def step(self):
-        # The exchange of step i (codes to every rank, 8*L bytes per clip; waveforms to rank 0, 18.4 MB per rank) is issued
-        # AFTER step i+1's encode_infer has been enqueued and collected before step i+1 returns: RCCL's kernels start
-        # once that encode has finished on the GPU and run beside the decode, never beside lstm_persist_kernel, which needs
-        # every CU for its resident workgroups (wavtokenizer_amd/csrc/lstm_persist.hip); the next encode is ordered
-        # behind the collective by its stream wait.
-        feats, codes = self.model.encode_infer(self.wav, bandwidth_id=self.bw)
-        pend = self._issue() if (self.gather and self.prev is not None) else None
-        out = self.model.decode(feats, bandwidth_id=self.bw)
-        res = pend.result() if pend is not None else None
-        if self.gather:
-            self.prev = (codes, out)
-        return codes, out, res
-
-    def drain(self):
-        """The exchange of the last step: issued and collected here, inside the timed region."""
-        if self.gather and self.prev is not None:
-            return self._issue().result()
-        return None
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,6 +183,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from wavtokenizer_amd import synth, _capi
+    from wavtokenizer_amd.sharding import StepRunner as Runner
 
     def barrier():
         torch.cuda.synchronize()
@@ -243,6 +207,8 @@ def main():
         if time_plan:
             _capi.check(_capi.lib.wt_plan_set_timing(time_plan[0], time_plan[1]), "wt_plan_set_timing")
         blocks = []
+        runner.own_blocks = []
+        runner.wait_s, runner.exchanges = 0.0, 0
         for _ in range(repeats):
             barrier()
             t0 = time.perf_counter()
@@ -250,7 +216,9 @@ def main():
                 runner.step()
             runner.drain()
             barrier()
-            blocks.append(max_over_ranks(time.perf_counter() - t0))
+            dt = time.perf_counter() - t0
+            runner.own_blocks.append(dt)                    # this rank's own clock; the line carries the MAX over ranks
+            blocks.append(max_over_ranks(dt))
         kern = None
         if time_plan:
             tot_ms, n_l = ctypes.c_double(), ctypes.c_int64()
@@ -273,6 +241,20 @@ def main():
     dplan = model._engine.plans[(_capi.WT_PLAN_DECODE, B, L, model._graph_flags(B))][0]
     blocks, kern = run_blocks(runner, args.steps, max(0, args.warmup - 1), args.repeats, (dplan, b"cnx.pwconv1"))
     model.check_status()
+    own_blocks = list(runner.own_blocks)
+
+    # N > 1: what every rank saw, so that the first run on a real multi-GPU node explains itself (rank 0 prints it)
+    ranks_info = None
+    if world > 1:
+        mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(dev), "device_index": dev.index,
+                "world_size_seen": dist.get_world_size(), "backend": dist.get_backend(),
+                "ms_per_step_own_clock": [round(1e3 * t / args.steps, 3) for t in own_blocks],
+                "exchange_wait_ms_per_step": round(1e3 * runner.wait_s / max(1, runner.exchanges), 3),
+                "exchanges": runner.exchanges,
+                "persistent_lstm": bool(getattr(model, "_plan_flags", 0) & _capi.WT_PLAN_FLAG_STEP_LSTM) is False}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        ranks_info = gathered
 
     p50_encode_ms = None
     if clip_s >= 30:       # BASELINE configs[4] also asks for the p50 latency of one encode_infer call
@@ -301,7 +283,11 @@ def main():
             "value": round(value, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "dtype_note": "fp32 storage and accumulation; dense layers form each fp32 product from split f16 operands (3 MFMAs, error below the fp32 chain's own rounding)",
+            "dtype_note": "fp32 accumulation everywhere; residual streams, norm / LSTM-cell arithmetic and outputs are fp32; every operand of a "
+                          "dense layer is STORED between layers as a split pair of f16 numbers (S32: x = hi + lo * 2^-11, 22 significant "
+                          "bits, f16 exponent range guarded by a status word) and each product is formed by 3 f16 MFMAs; the same workload "
+                          "on the plain fp32 MFMA chain is other_configs.fp32_gemm_chain_64x3s; measured error of both against a float64 "
+                          "run of the oracle: tests/test_gpu_parity.py::test_precision_against_float64 (profiles/r03_gpu_parity_summary.json)",
             "data": "synthetic",
             "timing": {"blocks": len(per_step), "steps_per_block": args.steps, "statistic": "median block",
                        "ms_per_step_min": round(per_step[0], 3), "ms_per_step_max": round(per_step[-1], 3),
@@ -312,7 +298,10 @@ def main():
                        "global_clips": world * B, "clip_seconds": clip_s, "frames_per_clip": L,
                        "codes_per_sec": round(world * B * L / (ms_per_step * 1e-3), 1),
                        **({"p50_encode_infer_ms_rank0": round(p50_encode_ms, 3)} if p50_encode_ms is not None else {}),
-                       "weights": "random-init (synth seed 0)", "model_load_s": round(load_s, 2), "parallelism": f"clips sharded dp{world}",
+                       "weights": "random-init (synth seed 0)", "model_load_s": round(load_s, 2),
+                       "hbm_weight_bytes": int(_capi.lib.wt_model_weight_bytes(model._engine.model)),
+                       "parallelism": f"clips sharded dp{world}",
+                       **({"ranks": ranks_info} if ranks_info is not None else {}),
                        "gather": ("codes all_gather + waveform gather to rank 0 (%s), asynchronous: step i's exchange runs beside step i+1's decode "
                                   "(never beside the persistent LSTM), all finished inside the timed region" % ("RCCL" if args.backend == "nccl" else "gloo rehearsal"))
                        if world > 1 and not args.no_gather else "none"},
@@ -382,6 +371,24 @@ def main():
             "audio_s_per_s_pipelined": round(audio_s / (pipelined_ms * len(lengths) / 1e3), 1),
             "plans_cached": len(model._engine.plans)}
         model.check_status()
+
+        # the headline workload on the plain fp32 MFMA chain (v_mfma_f32_32x32x2_f32 everywhere): same arithmetic type end to
+        # end, so the cost of fp32 products on the fp32 pipe is on the line beside the split-f16 path
+        model.set_gemm_precision("f32")
+        r32 = Runner(model, wav, bw, None, 1, 0, False, args.backend)
+        r32.step()
+        blk, _ = run_blocks(r32, 5, 1, 3)
+        ms32 = statistics.median(1e3 * t / 5 for t in blk)
+        model.check_status()
+        model.set_gemm_precision("f16x3")
+        model._engine.drop(lambda k: k[3] & _capi.WT_PLAN_FLAG_FP32_GEMM)
+        other["fp32_gemm_chain_64x3s"] = {
+            "what": "configs[1] with WT_PLAN_FLAG_FP32_GEMM: every dense layer on v_mfma_f32_32x32x2_f32 (fp32 operands in HBM, exact fp32 FMA chain)",
+            "ms_per_step": round(ms32, 3), "audio_s_per_s": round(B * clip_s / (ms32 * 1e-3), 1),
+            "end_to_end_tflops": round(gflop_per_clip(args.arch, arch, clip_s) * B * 1e9 / (ms32 * 1e-3) / 1e12, 2),
+            "end_to_end_frac_of_fp32_mfma_peak_157.3": round(gflop_per_clip(args.arch, arch, clip_s) * B * 1e9 / (ms32 * 1e-3) / 1e12 / 157.3, 4),
+            "steps": 5, "blocks": 3}
+        del r32
 
         # BASELINE configs[4], per-GPU share: hop-600, 32 clips x 30 s
         wav30 = torch.from_numpy(synth.make_clips(32, 30 * SAMPLE_RATE, seed=1000 * 4)).to(dev)

@@ -19,7 +19,8 @@
  *     time need distinct workspaces (the call's status word lives in the workspace).
  *   - a call that fails ON THE DEVICE (wt_status_bits) never hands out plausible data: the guard
  *     step that ends every plan overwrites its outputs (codes = -1, floats = NaN), and the next
- *     host call on the plan returns the matching error once, without running (see wt_plan_status).
+ *     host call on ANY plan of the same model returns the matching error once, without running
+ *     (wt_plan_status, wt_model_status): a caller that makes a new plan per input length still meets it.
  *   - activations inside the library are time-major [clip][frame][channel] fp32; the API
  *     tensors keep the reference's layouts (wav (B,T); features (B,512,L); codes (K,B,L) int64).
  */
@@ -40,10 +41,10 @@ typedef enum {
     WT_ERR_SHAPE = -3,
     WT_ERR_HIP = -4,          /* a HIP runtime call failed */
     WT_ERR_NOT_INITED = -5,   /* codebook buffer `inited` != 1 (core_vq.py:140-151 would run k-means) */
-    WT_ERR_RANGE = -6,        /* the PREVIOUS call on this plan met a value outside the f16 range of the split-f16 form; its
+    WT_ERR_RANGE = -6,        /* an EARLIER call on this model met a value outside the f16 range of the split-f16 form; its
                                  outputs were poisoned; re-plan with WT_PLAN_FLAG_FP32_GEMM and repeat both calls */
-    WT_ERR_LSTM_SYNC = -7,    /* the PREVIOUS call's persistent LSTM lost co-residency (a step barrier timed out); its outputs
-                                 were poisoned; the plan now runs the LSTM one launch per step: repeat both calls */
+    WT_ERR_LSTM_SYNC = -7,    /* an EARLIER call's persistent LSTM lost co-residency (a step barrier timed out); its outputs
+                                 were poisoned; every plan of the model now runs the LSTM one launch per step: repeat both calls */
     WT_ERR_INDEX = -8         /* a code outside [0, bins) (F.embedding raises IndexError: decoder/pretrained.py:236) */
 } wt_status;
 
@@ -115,13 +116,17 @@ void wt_model_destroy(wt_model* m);
 
 /* Packed weight image ("a packed on-disk weight format, folded, pre-tiled, for fast start"): everything
  * wt_model_create computes and leaves in HBM — weight-norm folded conv weights in [Cout][tap][Cin], LSTM gate-row
- * packings, the packed ISTFT head and inverse-DFT basis, the S32 / f16x2 split copies with their per-tensor scales —
- * behind a header (magic, layout version, the wt_arch, a hash of both).  wt_model_create_packed allocates, uploads and
- * fixes up pointers: nothing is folded, packed or split again (replaces the load_state_dict + per-forward weight_norm of
- * decoder/pretrained.py:95-114 a second time over).  wt_packed_info validates a header without a GPU. */
+ * packings, the packed ISTFT head and inverse-DFT basis, the S32 split copies with their per-tensor scales —
+ * behind a header (magic, layout version, the wt_arch, a hash of both, a hash of everything behind the header).
+ * wt_model_create_packed allocates, uploads and fixes up pointers: nothing is folded, packed or split again (replaces
+ * the load_state_dict + per-forward weight_norm of decoder/pretrained.py:95-114 a second time over).  The file is not
+ * trusted: sizes are checked without wrap-around, element counts are bounded, every pointer offset must lie inside
+ * its allocation, and the content hash must match before anything is uploaded.  wt_packed_info validates a header
+ * and wt_packed_verify the whole image (bounds + content hash) without a GPU. */
 size_t wt_model_export_bytes(const wt_model* m);
 int  wt_model_export(const wt_model* m, void* buf, size_t n);
 int  wt_packed_info(const void* buf, size_t n, wt_arch* arch, int32_t* version, uint64_t* arch_hash);
+int  wt_packed_verify(const void* buf, size_t n);
 int  wt_model_create_packed(const void* buf, size_t n, int32_t device, wt_model** out);
 int  wt_model_hop(const wt_model* m);                 /* prod(ratios) */
 int64_t wt_model_weight_bytes(const wt_model* m);     /* packed fp32 bytes resident in HBM */
@@ -142,9 +147,13 @@ int    wt_plan_find_buffer(const wt_plan* p, const char* name, size_t* offset, s
 int    wt_plan_buffer_info(const wt_plan* p, const char* name, size_t* offset, size_t* numel, int32_t* format);
 /* Device-side failure bits (wt_status_bits) that calls on this plan have reported since the last clear.  The bits of
  * a call are visible once its stream work has completed: synchronise first to learn about the call just made.
- * clear != 0 consumes them (and switches the plan to the launch-per-step LSTM after WT_STATUS_BIT_LSTM); bits left
- * unconsumed make the next wt_encode / wt_decode / ... on the plan return WT_ERR_LSTM_SYNC / WT_ERR_RANGE once. */
+ * clear != 0 consumes them together with the model's word (and switches the model to the launch-per-step LSTM after
+ * WT_STATUS_BIT_LSTM); bits left unconsumed make the next wt_encode / wt_decode / ... return WT_ERR_LSTM_SYNC /
+ * WT_ERR_RANGE once. */
 int    wt_plan_status(const wt_plan* p, int32_t* bits, int32_t clear);
+/* The same bits collected over ALL plans of the model (each plan's guard step reports into this word too, and it
+ * outlives plans that were destroyed): what the next call on any plan of the model will consume. */
+int    wt_model_status(const wt_model* m, int32_t* bits, int32_t clear);
 /* 1 when every GEMM weight fits the split-f16 form; 0: all plans of this model run the fp32 MFMA chain. */
 int    wt_model_split_ok(const wt_model* m);
 int    wt_plan_buffer_name(const wt_plan* p, int32_t index, const char** name);
@@ -206,11 +215,12 @@ int wt_sconv1d(const float* x, const float* w, const float* bias, float* y, int3
                void* stream);
 
 /* Replaces: nn.Linear.forward as used by ConvNeXtBlock.pwconv1/2 (decoder/modules.py:52,54): y [M][N] =
- * x [M][K] . w[N][K]^T + bias.  f16x3 = 0: fp32 MFMA chain; 1: the fp32-equivalent split-f16 kernel
- * (gemm16.hip; needs K % 32 == 0 and a workspace of 4*N*K bytes for the split weights); 2: the same arithmetic on
+ * x [M][K] . w[N][K]^T + bias.  f16x3 = 0: fp32 MFMA chain; 1: removed (round 1's in-loop split kernel); 2: the
+ * fp32-equivalent split-f16 arithmetic (x = hi + lo * 2^-11, three f16 MFMAs per product, fp32 accumulation) on
  * pre-split "S32" operands staged by LDS-DMA (gemm16s.hip: the plans' producers write S32 directly; here x and w
  * are split into the workspace first, 4*(M+N)*K bytes, K % 32 == 0); 3: as 2 and y is written in S32 too
- * (N % 32 == 0; every 32 outputs of a row = 128 bytes [32 x f16 hi | 32 x f16 lo], value = hi + lo * 2^-11).
+ * (N % 32 == 0; every 32 outputs of a row = 128 bytes [32 x f16 hi | 32 x f16 lo], value = hi + lo * 2^-11);
+ * 4: as 3 with the exact-erf GELU of decoder/modules.py:53 applied first (pwconv1's epilogue as the decode plan runs it).
  * Modes 2 / 3 need 8 KB more workspace (per-tensor scales; clock stamps of the timing-experiment builds). */
 int wt_linear(const float* x, const float* w, const float* bias, float* y, int64_t M, int32_t N, int32_t K,
               int32_t f16x3, void* workspace, void* stream);

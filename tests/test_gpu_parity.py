@@ -870,6 +870,9 @@ def test_activation_beyond_f16_range_is_loud_then_falls_back(gpu_model):
     bits = ctypes.c_int32()
     _capi.check(_capi.lib.wt_plan_status(plan, ctypes.byref(bits), 0), "wt_plan_status")
     assert bits.value & _capi.WT_STATUS_BIT_RANGE
+    mbits = ctypes.c_int32()
+    _capi.check(_capi.lib.wt_model_status(m._engine.model, ctypes.byref(mbits), 0), "wt_model_status")
+    assert mbits.value & _capi.WT_STATUS_BIT_RANGE         # the model's word carries it too (any plan's next call sees it)
     out2 = m.decode(big.cuda(), bandwidth_id=BW)           # WT_ERR_RANGE inside -> fp32 plan -> runs
     assert m._plan_flags & _capi.WT_PLAN_FLAG_FP32_GEMM
     e_big = rel_l2(out2.cpu().numpy(), want_big.numpy())
@@ -942,13 +945,28 @@ def test_codes_out_of_range_raise_like_embedding(gpu_model):
     """F.embedding raises IndexError on a code outside the codebook (decoder/pretrained.py:236); so does the drop-in."""
     name, m, _sd = gpu_model
     codes = torch.zeros(1, 2, 7, dtype=torch.int64, device="cuda")
-    m.codes_to_features(codes)
-    for bad in (4096, -1, 1 << 40):
-        c = codes.clone()
-        c[0, 1, 3] = bad
-        with pytest.raises(IndexError):
-            m.codes_to_features(c)
-    assert torch.isfinite(m.codes_to_features(codes)).all()      # the flag does not stick
+    m.set_check_codes("sync")
+    try:
+        m.codes_to_features(codes)
+        for bad in (4096, -1, 1 << 40):
+            c = codes.clone()
+            c[0, 1, 3] = bad
+            with pytest.raises(IndexError):
+                m.codes_to_features(c)
+        assert torch.isfinite(m.codes_to_features(codes)).all()      # the flag does not stick
+    finally:
+        m.set_check_codes("deferred")
+    # default mode: no stream synchronisation inside codes_to_features (the reference's CUDA F.embedding does not
+    # synchronise either); the bad index gives NaN features at once and IndexError on the next call or in check_status()
+    c = codes.clone()
+    c[0, 0, 2] = 5000
+    f = m.codes_to_features(c)
+    torch.cuda.synchronize()
+    assert torch.isnan(f[0, :, 2]).all() and torch.isfinite(f[1]).all()
+    with pytest.raises(IndexError):
+        m.codes_to_features(codes)
+    assert torch.isfinite(m.codes_to_features(codes)).all()
+    m.check_status()
 
 
 def test_graph_replay_single_clip_alternating_plans(gpu_model):
@@ -1010,3 +1028,233 @@ def test_packed_image_round_trip(gpu_model, tmp_path):
     with pytest.raises(RuntimeError):
         m2.state_dict()
     parity_log.record(f"packed_load[{name}]", image_mb=img1.nbytes / 1e6, from_packed_s=t_packed, from_state_dict_s=t_state)
+
+
+# ------------------------------------------------------------------------------------------ round 3
+def _fresh_model(name, sd):
+    from wavtokenizer_amd import WavTokenizer, NAMED_ARCHS
+    m = WavTokenizer.from_arch(NAMED_ARCHS[name])
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    return m.eval().to("cuda")
+
+
+def test_precision_against_float64(gpu_model):
+    """What "fp32-equivalent" means end to end, measured: the oracle runs in FLOAT64 (same op sequence, weights and inputs
+    cast up) and three fp32-class implementations are compared with it on the b2 fixture inputs: the CPU fp32 oracle
+    (= the reference), the shipped GPU path (split-f16 products, S32 operands between dense layers) and the GPU's plain
+    fp32 MFMA chain (WT_PLAN_FLAG_FP32_GEMM).  Recorded per arch: rel-L2 of the encoder output (pre-VQ), of the decoded
+    waveform (same features on every side), and code agreement.  Bar: the shipped path's error stays within 4x the CPU
+    fp32 oracle's own error (both are rounding noise around the same real-arithmetic result), and far inside 1e-4."""
+    from tests import parity_log
+    name, m, sd = gpu_model
+    g = load_case(name, "b2_t72000")
+    wav_np = g["wav_in"]
+    o32 = _oracle(name, sd)
+    from oracle.cpu_ref import OracleWavTokenizer
+    from wavtokenizer_amd import NAMED_ARCHS
+    o64 = OracleWavTokenizer(NAMED_ARCHS[name], {k: torch.from_numpy(v).double() for k, v in sd.items()})
+    t32, t64 = {}, {}
+    with torch.inference_mode():
+        f32, c32 = o32.encode_infer(torch.from_numpy(wav_np), BW, t32)
+        f64, c64 = o64.encode_infer(torch.from_numpy(wav_np).double(), BW, t64)
+        w64 = o64.decode(f32.double(), BW)              # the same (fp32 oracle's) features on every side
+        w32 = o32.decode(f32, BW)
+    emb_key = max((k for k in t64 if k.startswith("enc.")), key=lambda k: int(k.split(".")[1]))     # last encoder tap = pre-VQ embedding
+    e64 = t64[emb_key].numpy()
+    res = {"cpu_fp32_oracle": {"emb": rel_l2(t32[emb_key].numpy(), e64), "wav": rel_l2(w32.numpy(), w64.numpy()),
+                               "codes_equal_fp64": bool(torch.equal(c32, c64))}}
+    wav = torch.from_numpy(wav_np).cuda()
+    for label, mode in (("gpu_f16x3_shipped", "f16x3"), ("gpu_fp32_chain", "f32")):
+        m.set_gemm_precision(mode)
+        try:
+            emb = m.feature_extractor.encodec.encoder(wav.unsqueeze(1)).cpu().numpy()
+            _f, codes = m.encode_infer(wav, bandwidth_id=BW)
+            wg = m.decode(f32.cuda(), bandwidth_id=BW).cpu().numpy()
+        finally:
+            m.set_gemm_precision("f16x3")
+        res[label] = {"emb": rel_l2(emb, e64), "wav": rel_l2(wg, w64.numpy()), "codes_equal_fp64": bool(torch.equal(codes.cpu(), c64))}
+    m.check_status()
+    ratio_wav = res["gpu_f16x3_shipped"]["wav"] / res["cpu_fp32_oracle"]["wav"]
+    ratio_emb = res["gpu_f16x3_shipped"]["emb"] / res["cpu_fp32_oracle"]["emb"]
+    parity_log.record(f"vs_float64[{name}]", **{f"{k}.{kk}": vv for k, v in res.items() for kk, vv in v.items()},
+                      shipped_over_cpu_fp32_wav=ratio_wav, shipped_over_cpu_fp32_emb=ratio_emb)
+    print(f"[{name}] vs float64: {res}")
+    assert all(v["codes_equal_fp64"] for v in res.values()), res
+    assert res["gpu_f16x3_shipped"]["wav"] < 2e-5 and res["gpu_f16x3_shipped"]["emb"] < 2e-5, res
+    assert ratio_wav < 4.0 and ratio_emb < 4.0, res
+
+
+def test_30s_batch32():
+    """BASELINE configs[4] at its per-GPU batch: 32 clips x 30 s (L = 1200).  The fixture clip (hop600_b1_t720000, captured
+    from the reference) sits in slot k of a batch of other clips: its codes must equal the fixture's (so the result of a
+    clip does not depend on its slot or its neighbours: 4 clips per XCD in lstm_persist, the chunked GroupNorm, the long
+    attention), its waveform head / tail / norm must match, the status word stays clean; p50 encode latency is recorded."""
+    import time
+    from wavtokenizer_amd import synth
+    from tests import parity_log
+    m, _sd = _model("hop600")
+    g = load_case("hop600", "b1_t720000")
+    fill = synth.make_clips(32, 720000, seed=3100)
+    ref_codes = None
+    lat = []
+    for k in (0, 17, 31):
+        batch = fill.copy()
+        batch[k] = g["wav_in"][0]
+        wav = torch.from_numpy(batch).cuda()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        feats, codes = m.encode_infer(wav, bandwidth_id=BW)
+        torch.cuda.synchronize()
+        lat.append(1e3 * (time.perf_counter() - t0))
+        out = m.decode(feats, bandwidth_id=BW)
+        ck = codes[:, k:k + 1].cpu().numpy()
+        assert check_codes(ck, g["codes"], g["margin"], f"30s slot {k}") == 0
+        o = out[k:k + 1].cpu().numpy()
+        assert rel_l2(o[:, :4096], g["wav_out_head"]) < WAV_REL_TOL, k
+        assert rel_l2(o[:, -4096:], g["wav_out_tail"]) < WAV_REL_TOL, k
+        assert abs(np.sqrt((o.astype(np.float64) ** 2).sum()) - float(g["wav_out_l2"])) < WAV_REL_TOL * float(g["wav_out_l2"])
+        # the other 31 clips do not depend on slot k either: clips outside {0, 17, 31} are identical in all three batches
+        others = codes[:, 1:17].cpu()
+        if ref_codes is None:
+            ref_codes = others
+        assert torch.equal(others, ref_codes), k
+        assert torch.isfinite(out).all()
+    m.check_status()
+    parity_log.record("batch32x30s[hop600]", slots=3, encode_ms_first=lat[0], encode_ms_p50=sorted(lat)[1])
+
+
+@pytest.mark.parametrize("name", ["hop600", "hop320"])
+def test_trained_like_weights(name):
+    """Weights with the statistics of a trained checkpoint instead of an init (synth.make_trained_like_state_dict: log-normal
+    weight_g, heavy-tailed matrices with outliers, layer scale up to 10, spread norm scales; no trained checkpoint exists
+    offline).  Fixture = the reference's outputs on them (tests/golden/make_golden_trained_like.py).  The shipped path and
+    the fp32 chain are both held to the usual bars, and it is recorded whether the f16-range guard fired."""
+    import os
+    from wavtokenizer_amd import NAMED_ARCHS, synth
+    from tests.util import GOLDEN
+    from tests import parity_log
+    g = np.load(os.path.join(GOLDEN, f"{name}_trained_like.npz"))
+    sd = synth.make_trained_like_state_dict(NAMED_ARCHS[name], seed=int(g["weight_seed"]))
+    bw = torch.tensor([int(g["bandwidth_id"])])
+    wav = torch.from_numpy(g["wav_in"]).cuda()
+    rec = {}
+    for label, mode in (("f16x3", "f16x3"), ("fp32_chain", "f32")):
+        m = _fresh_model(name, sd)
+        m.set_gemm_precision(mode)
+        feats, codes = m.encode_infer(wav, bandwidth_id=bw)
+        out = m.decode(feats, bandwidth_id=bw)
+        torch.cuda.synchronize()
+        fired = False
+        try:
+            m.check_status()
+        except Exception:                      # the range guard fired: the class has switched to fp32 GEMMs, repeat
+            fired = True
+            feats, codes = m.encode_infer(wav, bandwidth_id=bw)
+            out = m.decode(feats, bandwidth_id=bw)
+            m.check_status()
+        flips = check_codes(codes.cpu().numpy(), g["codes"], g["margin"], f"trained-like {name} {label}")
+        err = rel_l2(out.cpu().numpy(), g["wav_out"]) if flips == 0 else float("nan")
+        rec[label] = (flips, err, fired)
+        assert flips == 0 and err < WAV_REL_TOL, (label, flips, err)
+    parity_log.record(f"trained_like[{name}]", code_flips=rec["f16x3"][0], frames=int(g["codes"].size), wav_rel_l2=rec["f16x3"][1],
+                      range_guard_fired=rec["f16x3"][2], wav_rel_l2_fp32_chain=rec["fp32_chain"][1], min_margin=float(g["margin"].min()))
+
+
+def test_device_failure_reaches_the_next_call_on_another_plan(gpu_model):
+    """A file-by-file caller (infer.py: one clip per call, a new length and so a new plan per file) never uses a plan twice:
+    the failure of one call must surface on the NEXT call on the model whatever its shape, and the fallback must stick
+    for the whole model.  First call (length A): persistent LSTM forced to fail -> poisoned outputs.  Second call
+    (length B, a different plan): returns correct results from the step kernel without another timeout, and a third
+    plan (length C) does not launch the persistent kernel again."""
+    import os
+    import time
+    from wavtokenizer_amd import synth, _capi
+    name, _m, sd = gpu_model
+    m = _fresh_model(name, sd)
+    m.set_graph_max_clips(0)
+    A, Bl, C = 7200, 9000, 10100
+    wa, wb, wc = (torch.from_numpy(synth.make_clips(3, T, seed=620 + T)).cuda() for T in (A, Bl, C))
+    m.set_lstm_mode("step")
+    try:
+        refs = [m.encode_infer(w, bandwidth_id=BW) for w in (wb, wc)]
+    finally:
+        m.set_lstm_mode("persistent")
+    m._engine.drop(lambda k: True)
+    os.environ["WT_LSTM_PERSIST_FAULT"] = "1"
+    try:
+        f1, c1 = m.encode_infer(wa, bandwidth_id=BW)
+        torch.cuda.synchronize()
+        assert int(c1.max()) == -1 and torch.isnan(f1).all()
+        # the fault hook is still armed: a second persistent launch would time out again and poison this call too
+        t0 = time.perf_counter()
+        f2, c2 = m.encode_infer(wb, bandwidth_id=BW)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t0
+        f3, c3 = m.encode_infer(wc, bandwidth_id=BW)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["WT_LSTM_PERSIST_FAULT"]
+    assert torch.equal(c2, refs[0][1]) and torch.equal(f2, refs[0][0]), "the next call on another plan must fall back and be correct"
+    assert torch.equal(c3, refs[1][1]) and torch.equal(f3, refs[1][0])
+    m.check_status()                                    # nothing left pending: every failure was consumed and answered
+    assert dt2 < 5.0
+
+
+def test_bandwidth_id_tensor_created_under_inference_mode(gpu_model):
+    """infer.py builds bandwidth_id on the GPU; a tensor created under torch.inference_mode() has no version counter."""
+    name, m, _sd = gpu_model
+    feats = torch.randn(1, 512, 20, generator=torch.Generator().manual_seed(3)).cuda()
+    want = m.decode(feats, bandwidth_id=torch.tensor([1]))
+    with torch.inference_mode():
+        bw = torch.tensor([1]).cuda()
+        got = m.decode(feats, bandwidth_id=bw)
+        got2 = m.decode(feats, bandwidth_id=bw)
+    assert torch.equal(got, want) and torch.equal(got2, want)
+    bw_plain = torch.tensor([1]).cuda()                 # the cached path (a normal tensor, same object passed twice)
+    assert torch.equal(m.decode(feats, bandwidth_id=bw_plain), want) and torch.equal(m.decode(feats, bandwidth_id=bw_plain), want)
+
+
+def test_corrupt_packed_images_are_refused(gpu_model):
+    """The packed image is not trusted: truncation, a flipped payload bit, a flipped bit in the model section and a pointer
+    offset outside its allocation all end in an error return (never a crash, never a model that faults later)."""
+    import ctypes
+    from wavtokenizer_amd import _capi
+    name, m, _sd = gpu_model
+    img = m._engine.export()
+    lib = _capi.lib
+
+    def load(buf):
+        h = ctypes.c_void_p()
+        rc = lib.wt_model_create_packed(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes, torch.cuda.current_device(), ctypes.byref(h))
+        if rc == 0:
+            lib.wt_model_destroy(h)
+        return rc, lib.wt_last_error().decode()
+
+    assert load(img)[0] == 0
+    assert lib.wt_packed_verify(img.ctypes.data_as(ctypes.c_void_p), img.nbytes) == 0
+    for cut in (img.nbytes - 1, img.nbytes // 2, 4096, 100):
+        rc, msg = load(img[:cut].copy())
+        assert rc != 0, cut
+    flip = img.copy()
+    flip[img.nbytes - 12345] ^= 0x10                     # payload
+    rc, msg = load(flip)
+    assert rc != 0 and "hash" in msg, msg
+    flip = img.copy()
+    flip[128 + 8 * 4 + 40] ^= 0x01                      # allocation table / model section
+    assert load(flip)[0] != 0
+    # a consistent-looking file (hash recomputed is not possible from here): at least the verify entry point agrees
+    assert lib.wt_packed_verify(flip.ctypes.data_as(ctypes.c_void_p), flip.nbytes) != 0
+
+
+def test_batch_beyond_the_persistent_lstm_limit(gpu_model):
+    """More than 128 clips per call do not fit the persistent LSTM's per-XCD clip groups (16 per XCD): the plan then runs the
+    launch-per-step kernel (documented in DESIGN section 7).  Results must not depend on that: 130 clips in one call equal
+    the same clips in two calls of 65."""
+    from wavtokenizer_amd import synth
+    name, m, _sd = gpu_model
+    wav = torch.from_numpy(synth.make_clips(130, 4800, seed=1300)).cuda()
+    f, c = m.encode_infer(wav, bandwidth_id=BW)
+    fa, ca = m.encode_infer(wav[:65].contiguous(), bandwidth_id=BW)
+    fb, cb = m.encode_infer(wav[65:].contiguous(), bandwidth_id=BW)
+    assert torch.equal(c, torch.cat([ca, cb], dim=1)) and torch.equal(f, torch.cat([fa, fb], dim=0))
+    m.check_status()

@@ -281,3 +281,141 @@ def test_bench_finds_the_dominant_kernel_in_the_committed_pmc_summary():
     spec.loader.exec_module(bench)
     t = bench.pmc_traffic("hop600", 64, 3)
     assert t is not None and 101e6 < t < 400e6, t
+
+
+# ------------------------------------------------------------------------------------------ round 3
+class _RecordingCodec:
+    """Deterministic stand-in for the GPU model in the world-2 test of the step runner: per-clip, batch-independent
+    results, and every enqueue is visible in the runner's log (StepRunner logs encode / issue / decode / collect)."""
+    hop = 600
+
+    def encode_infer(self, wav, bandwidth_id=None):
+        codes = (wav[:, ::self.hop].abs() * 4095).long().clamp_(0, 4095).unsqueeze(0)
+        return wav[:, None, ::self.hop].repeat(1, 512, 1), codes
+
+    def decode(self, feats, bandwidth_id=None):
+        return feats[:, 0, :].repeat_interleave(self.hop, dim=1)
+
+
+def _runner_worker(rank, world, port, n_steps, q):
+    import torch.distributed as dist
+    from wavtokenizer_amd.sharding import StepRunner, check_exchange_order, shard_bounds
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(1)
+    wav_all = torch.rand(6, 3000, generator=g)
+    lo, hi = shard_bounds(6, rank, world)
+    log = []
+    model = _RecordingCodec()
+    r = StepRunner(model, wav_all[lo:hi].contiguous(), torch.tensor([0]), dist, world, rank, gather=True, backend="gloo", log=log)
+    results = []
+    for _ in range(n_steps):
+        _c, _o, res = r.step()
+        if res is not None:
+            results.append(res)
+    results.append(r.drain())
+    ok = True
+    try:
+        check_exchange_order(log, n_steps)
+    except AssertionError as e:
+        ok = False
+        log.append(("order-violation", str(e)))
+    f, c = model.encode_infer(wav_all)
+    want_wav = model.decode(f)
+    for codes, wav in results:                 # every exchange delivers all clips in clip order
+        ok = ok and torch.equal(codes, c) and (rank != 0 or torch.equal(wav, want_wav)) and (rank == 0 or wav is None)
+    ok = ok and len(results) == n_steps and r.exchanges == n_steps
+    q.put((rank, bool(ok), log))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_step_runner_exchange_order_world2_gloo():
+    """The ordering argument of bench.py --gpus N, asserted instead of rehearsed by hand: the exchange of
+    step i is issued after step i+1's encode has been enqueued and collected before step i+2's encode, so RCCL's kernels
+    can never run beside the persistent LSTM; every exchange delivers all clips in order; the last one is drained."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    n_steps = 4
+    procs = [ctx.Process(target=_runner_worker, args=(r, 2, port, n_steps, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
+    # the invariant checker itself rejects the wrong order (an exchange issued before the next encode)
+    from wavtokenizer_amd.sharding import check_exchange_order
+    bad = [("encode", 0), ("decode", 0), ("issue", 0), ("encode", 1), ("decode", 1), ("collect", 0), ("issue", 1), ("collect", 1)]
+    with pytest.raises(AssertionError):
+        check_exchange_order(bad, 2)
+
+
+def _packed_header(arch, version=None, n_allocs=0, struct_bytes=0, payload_bytes=0, total=4096):
+    """A packed-image header as weights.cpp lays it out (magic, version, wt_arch, FNV-1a hash of both, sizes, body hash)."""
+    import numpy as np
+    from wavtokenizer_amd import _capi
+    wa = _capi.WtArch()
+    wa.n_ratios = len(arch.ratios)
+    for i, r in enumerate(arch.ratios):
+        wa.ratios[i] = r
+    wa.vq_bins, wa.num_quantizers, wa.input_channels = arch.vq_bins, arch.num_quantizers, arch.input_channels
+    wa.dim, wa.intermediate_dim, wa.num_layers = arch.dim, arch.intermediate_dim, arch.num_layers
+    wa.adanorm_num_embeddings, wa.n_fft, wa.hop_length = arch.adanorm_num_embeddings, arch.n_fft, arch.hop_length
+    wa.padding_same = 1 if arch.padding == "same" else 0
+    if version is None:          # ask the library which layout version it reads
+        probe = np.zeros(4096, np.uint8)
+        probe[:4] = np.frombuffer(b"WTPK", dtype=np.uint8)
+        probe[4:8] = np.frombuffer(np.int32(1).tobytes(), dtype=np.uint8)
+        _capi.lib.wt_packed_info(probe.ctypes.data_as(ctypes.c_void_p), probe.nbytes, None, None, None)
+        version = int(re.search(r"this library reads (\d+)", _capi.lib.wt_last_error().decode()).group(1))
+    arch_bytes = bytes(wa)
+    h = 1469598103934665603
+    for byte in arch_bytes + np.int32(version).tobytes():
+        h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    buf = np.zeros(total, np.uint8)
+    hdr = b"WTPK" + np.int32(version).tobytes() + arch_bytes
+    hdr += bytes((-len(hdr)) % 8)
+    hdr += np.array([h, n_allocs, struct_bytes, payload_bytes, 0], dtype=np.uint64).tobytes()
+    buf[:len(hdr)] = np.frombuffer(hdr, dtype=np.uint8)
+    return buf
+
+
+def test_from_packed_rejects_any_architecture_mismatch(tmp_path):
+    """The C side sizes its launches from the image's wt_arch, the Python class its tensors from the YAML: a 'same' image
+    under a 'center' config would be written past the end of the waveform tensor.  Every field is compared (no GPU needed:
+    the check runs on the header before anything is uploaded)."""
+    import dataclasses
+    import yaml
+    from wavtokenizer_amd import WavTokenizer, NAMED_ARCHS
+    base = NAMED_ARCHS["hop600"]
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text(yaml.safe_dump({"model": {"init_args": base.to_yaml_node()}}))
+    for field, value in (("padding", "center"), ("adanorm_num_embeddings", 2), ("num_layers", 8), ("vq_bins", 1024)):
+        other = dataclasses.replace(base, **{field: value})
+        img = tmp_path / f"{field}.wtpk"
+        _packed_header(other).tofile(str(img))
+        with pytest.raises(ValueError, match=field):
+            WavTokenizer.from_packed(str(cfg), str(img))
+
+
+def test_packed_header_sizes_cannot_wrap():
+    """Header sizes are attacker-controlled: huge values must read as 'truncated', never wrap around size_t."""
+    from wavtokenizer_amd import _capi, NAMED_ARCHS
+    lib = _capi.lib
+    arch = NAMED_ARCHS["hop600"]
+
+    def info(buf):
+        rc = lib.wt_packed_info(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes, None, None, None)
+        return rc, lib.wt_last_error().decode()
+
+    assert info(_packed_header(arch))[0] == 0                                   # a well-formed empty header passes the header check
+    for kw in ({"struct_bytes": 2 ** 64 - 64}, {"struct_bytes": 2 ** 63}, {"n_allocs": 2 ** 61}, {"n_allocs": 2 ** 64 - 1},
+               {"payload_bytes": 2 ** 64 - 256}, {"payload_bytes": 10 ** 9}, {"n_allocs": 3, "struct_bytes": 4096}):
+        rc, msg = info(_packed_header(arch, **kw))
+        assert rc != 0 and "truncated" in msg, (kw, msg)
+    # the full check also hashes the body: a header-only image with a zero hash field is refused
+    buf = _packed_header(arch)
+    assert lib.wt_packed_verify(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes) != 0
+    assert "hash" in lib.wt_last_error().decode()

@@ -57,10 +57,11 @@ def main():
                 ghz = (st[ok, 0] / st[ok, 1] * 0.1).median().item()
                 print(f"   in-kernel clock (median over {int(ok.sum())} workgroups): {ghz:.3f} GHz", flush=True)
                 label = f"{label} [{ghz:.2f} GHz]"
-        out = decode_s32(y, M, N) if mode == 3 else y
-        ref = x[:1024].double() @ w.double().t() + b.double()
+        out = decode_s32(y, M, N) if mode >= 3 else y
+        act = (lambda v: torch.nn.functional.gelu(v)) if mode == 4 else (lambda v: v)
+        ref = act(x[:1024].double() @ w.double().t() + b.double())
         err = ((out[:1024].double() - ref).norm() / ref.norm()).item()
-        ref2 = x[-256:].double() @ w.double().t() + b.double()
+        ref2 = act(x[-256:].double() @ w.double().t() + b.double())
         err = max(err, ((out[-256:].double() - ref2).norm() / ref2.norm()).item())
         calls.append({"label": label, "n": WARM + REPS, "warm": WARM, "flop": 2.0 * M * N * K, "err": err})
         print(label, "err", err, flush=True)
@@ -110,6 +111,18 @@ def main():
                             (45, "MFMA + LDS fragment reads"), (61, "MFMA only"), (21, "no epilogue, no DMA, no LDS reads"), (64, "full, younger half at priority 1")):
                 os.environ["WT_GEMM16S_DBG"] = str(dbg)
                 linear(f"pwconv1 {mn}: {dn}", 7680, 2304, 768, mode, 2)
+                os.environ.pop("WT_GEMM16S_DBG")
+        json.dump(calls, open(sys.argv[1], "w"))
+        return
+    if len(sys.argv) > 2 and sys.argv[2] == "dbg2":        # the 8-wave tile against the 4-wave / 512-register one, rung by rung
+        WARM, REPS = 30, 40
+        for tile in (2, 10):
+            linear(f"pwconv1 bias->fp32 tile {tile} shipped", 7680, 2304, 768, 2, tile)
+            linear(f"pwconv1 bias->S32 tile {tile} shipped", 7680, 2304, 768, 3, tile)
+            linear(f"pwconv1 gelu->S32 tile {tile} shipped", 7680, 2304, 768, 4, tile)
+            for dbg, dn in ((1024, "full (stamped)"), (4, "no epilogue"), (5, "no epilogue, no DMA"), (45, "MFMA + LDS fragment reads")):
+                os.environ["WT_GEMM16S_DBG"] = str(dbg)
+                linear(f"pwconv1 bias->fp32 tile {tile}: {dn}", 7680, 2304, 768, 2, tile)
                 os.environ.pop("WT_GEMM16S_DBG")
         json.dump(calls, open(sys.argv[1], "w"))
         return

@@ -15,11 +15,11 @@ LIB_PATH = os.environ.get("WAVTOK_HIP_LIB") or os.path.join(_HERE, "libwavtok_hi
 
 # every symbol include/wavtokenizer_amd.h declares
 EXPORTS = [
-    "wt_last_error", "wt_version", "wt_model_create", "wt_model_destroy", "wt_model_export_bytes", "wt_model_export", "wt_packed_info",
+    "wt_last_error", "wt_version", "wt_model_create", "wt_model_destroy", "wt_model_export_bytes", "wt_model_export", "wt_packed_info", "wt_packed_verify",
     "wt_model_create_packed", "wt_model_hop", "wt_model_weight_bytes",
     "wt_plan_create", "wt_plan_destroy", "wt_plan_workspace_bytes", "wt_plan_frames", "wt_plan_num_launches", "wt_plan_graph_replays",
     "wt_plan_find_buffer", "wt_plan_buffer_info", "wt_plan_buffer_name", "wt_plan_status", "wt_plan_num_steps", "wt_plan_step_name",
-    "wt_plan_set_timing", "wt_plan_read_timing", "wt_model_split_ok", "wt_model_take_bad_codes", "wt_encode", "wt_codes_to_features",
+    "wt_plan_set_timing", "wt_plan_read_timing", "wt_model_split_ok", "wt_model_status", "wt_model_take_bad_codes", "wt_encode", "wt_codes_to_features",
     "wt_decode", "wt_seanet_decode", "wt_head", "wt_unit_run", "wt_sconv1d", "wt_linear", "wt_conv1d_s32", "wt_vq_workspace_bytes",
     "wt_vq_nearest", "wt_vq_nearest_f32", "wt_resblock", "wt_resblock_down",
     "wt_resampler_create", "wt_resampler_destroy", "wt_resampler_out_length", "wt_convert_audio", "wt_pcm16",
@@ -69,6 +69,7 @@ def _load() -> ctypes.CDLL:
     lib.wt_model_export_bytes.restype = c_size_t
     lib.wt_model_export.argtypes = [c_void_p, c_void_p, c_size_t]
     lib.wt_packed_info.argtypes = [c_void_p, c_size_t, POINTER(WtArch), POINTER(c_int32), POINTER(ctypes.c_uint64)]
+    lib.wt_packed_verify.argtypes = [c_void_p, c_size_t]
     lib.wt_model_create_packed.argtypes = [c_void_p, c_size_t, c_int32, POINTER(c_void_p)]
     lib.wt_model_hop.argtypes = [c_void_p]
     lib.wt_model_weight_bytes.argtypes = [c_void_p]
@@ -87,6 +88,7 @@ def _load() -> ctypes.CDLL:
     lib.wt_plan_buffer_info.argtypes = [c_void_p, c_char_p, POINTER(c_size_t), POINTER(c_size_t), POINTER(c_int32)]
     lib.wt_plan_status.argtypes = [c_void_p, POINTER(c_int32), c_int32]
     lib.wt_model_split_ok.argtypes = [c_void_p]
+    lib.wt_model_status.argtypes = [c_void_p, POINTER(c_int32), c_int32]
     lib.wt_model_take_bad_codes.argtypes = [c_void_p]
     lib.wt_unit_run.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.wt_plan_buffer_name.argtypes = [c_void_p, c_int32, POINTER(c_char_p)]

@@ -10,6 +10,23 @@ thread_local LaunchCtx g_launch;
 // ================================================================================== C ABI
 using namespace wt;
 
+// one host-mapped block per model: word 0 = wt_codes_to_features' bad-index flag, word 16 = the model-level call status
+static int alloc_host_words(wt_model* M, const char* who) {
+    void* hp = nullptr;
+    void* dp = nullptr;
+    if (hipHostMalloc(&hp, 256, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+        if (hp) (void)hipHostFree(hp);
+        set_error(std::string(who) + ": no host-mapped memory for the status words");
+        return WT_ERR_HIP;
+    }
+    memset(hp, 0, 256);
+    M->bad_codes_host = static_cast<unsigned*>(hp);
+    M->bad_codes_dev = static_cast<unsigned*>(dp);
+    M->status_host = static_cast<unsigned*>(hp) + 16;
+    M->status_dev = static_cast<unsigned*>(dp) + 16;
+    return WT_OK;
+}
+
 extern "C" {
 
 const char* wt_last_error(void) { return g_err.c_str(); }
@@ -34,19 +51,7 @@ int wt_model_create(const wt_arch* arch, const wt_tensor* tensors, int32_t n_ten
     for (int i = 0; i < n_tensors; ++i) tm.m[tensors[i].name] = {tensors[i].data, tensors[i].numel};
     int rc = build_model(M.get(), tm);
     if (!rc) rc = build_splits(M.get());
-    if (!rc) {
-        void* hp = nullptr;
-        void* dp = nullptr;
-        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
-            if (hp) (void)hipHostFree(hp);
-            set_error("wt_model_create: no host-mapped memory for the status word");
-            rc = WT_ERR_HIP;
-        } else {
-            M->bad_codes_host = static_cast<unsigned*>(hp);
-            M->bad_codes_dev = static_cast<unsigned*>(dp);
-            *M->bad_codes_host = 0;
-        }
-    }
+    if (!rc) rc = alloc_host_words(M.get(), "wt_model_create");
     if (rc) {
         if (rc == WT_ERR_MISSING_TENSOR) set_error("state_dict tensor missing or mis-shaped: " + tm.missing);
         for (void* p : M->allocs) (void)hipFree(p);
@@ -66,6 +71,10 @@ int wt_model_export(const wt_model* m, void* buf, size_t n) {
 int wt_packed_info(const void* buf, size_t n, wt_arch* arch, int32_t* version, uint64_t* arch_hash) {
     return packed_info(buf, n, arch, version, arch_hash);
 }
+int wt_packed_verify(const void* buf, size_t n) {
+    try { return packed_verify(buf, n); }
+    catch (const std::exception& e) { set_error(std::string("wt_packed_verify: ") + e.what()); return WT_ERR_INVALID; }
+}
 int wt_model_create_packed(const void* buf, size_t n, int32_t device, wt_model** out) {
     if (!buf || !out) { set_error("wt_model_create_packed: null argument"); return WT_ERR_INVALID; }
     if (int rc = packed_info(buf, n, nullptr, nullptr, nullptr)) return rc;
@@ -73,20 +82,10 @@ int wt_model_create_packed(const void* buf, size_t n, int32_t device, wt_model**
     if (!dg.ok) { set_error("wt_model_create_packed: hipSetDevice failed"); return WT_ERR_HIP; }
     std::unique_ptr<wt_model> M(new wt_model());
     M->device = device;
-    int rc = model_import(M.get(), buf, n);
-    if (!rc) {
-        void* hp = nullptr;
-        void* dp = nullptr;
-        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
-            if (hp) (void)hipHostFree(hp);
-            set_error("wt_model_create_packed: no host-mapped memory for the status word");
-            rc = WT_ERR_HIP;
-        } else {
-            M->bad_codes_host = static_cast<unsigned*>(hp);
-            M->bad_codes_dev = static_cast<unsigned*>(dp);
-            *M->bad_codes_host = 0;
-        }
-    }
+    int rc;
+    try { rc = model_import(M.get(), buf, n); }      // nothing may throw across the C boundary (a bad file must not end the process)
+    catch (const std::exception& e) { set_error(std::string("wt_model_create_packed: ") + e.what()); rc = WT_ERR_INVALID; }
+    if (!rc) rc = alloc_host_words(M.get(), "wt_model_create_packed");
     if (rc) {
         for (void* p : M->allocs) (void)hipFree(p);
         return rc;
@@ -107,6 +106,14 @@ int wt_model_take_bad_codes(const wt_model* m) {
     if (!m || !m->bad_codes_host) return 0;
     const unsigned v = __atomic_exchange_n(m->bad_codes_host, 0u, __ATOMIC_RELAXED);
     return v ? 1 : 0;
+}
+int wt_model_status(const wt_model* m, int32_t* bits, int32_t clear) {
+    if (!m) return WT_ERR_INVALID;
+    unsigned b = 0;
+    if (m->status_host) b = clear ? __atomic_exchange_n(m->status_host, 0u, __ATOMIC_ACQUIRE) : __atomic_load_n(m->status_host, __ATOMIC_ACQUIRE);
+    if (b & WT_STATUS_LSTM) m->persist_ok.store(false);
+    if (bits) *bits = (int32_t)b;
+    return WT_OK;
 }
 int wt_model_hop(const wt_model* m) { return m ? m->hop : 0; }
 int64_t wt_model_weight_bytes(const wt_model* m) { return m ? m->weight_bytes : 0; }
@@ -141,14 +148,14 @@ int wt_plan_create(const wt_model* m, int32_t kind, int32_t B, int64_t len, int3
         rc = build_encode(P.get());
     } else if (kind == WT_PLAN_DECODE) {
         P->L = len; P->T = len * m->hop;
-        if (!m->arch.padding_same && len < 2) { set_error("ISTFT padding='center' needs at least two frames"); (void)hipHostFree(P->status_host); return WT_ERR_INVALID; }
+        if (!m->arch.padding_same && len < 2) { set_error("ISTFT padding='center' needs at least two frames"); return WT_ERR_INVALID; }
         rc = build_decode(P.get());
     } else if (kind == WT_PLAN_SEANET_DECODER) {
         P->L = len; P->T = len * m->hop;
         rc = build_seanet_decoder(P.get());
     } else if (kind == WT_PLAN_HEAD) {
         P->L = len; P->T = len * m->hop;
-        if (!m->arch.padding_same && len < 2) { set_error("ISTFT padding='center' needs at least two frames"); (void)hipHostFree(P->status_host); return WT_ERR_INVALID; }
+        if (!m->arch.padding_same && len < 2) { set_error("ISTFT padding='center' needs at least two frames"); return WT_ERR_INVALID; }
         rc = build_head(P.get());
     } else if (kind == WT_PLAN_UNIT_LSTM) {
         P->L = len; P->T = len * m->hop;
@@ -156,7 +163,7 @@ int wt_plan_create(const wt_model* m, int32_t kind, int32_t B, int64_t len, int3
     } else {
         set_error("unknown plan kind"); rc = WT_ERR_INVALID;
     }
-    if (rc) { (void)hipHostFree(P->status_host); return rc; }
+    if (rc) return rc;              // ~wt_plan releases the host-mapped word
     plan_end(P.get());
     P->layout();
     *out = P.release();
@@ -164,11 +171,7 @@ int wt_plan_create(const wt_model* m, int32_t kind, int32_t B, int64_t len, int3
 }
 void wt_plan_destroy(wt_plan* p) {
     if (!p) return;
-    if (p->status_host) (void)hipHostFree(p->status_host);
-    if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
-    if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
-    for (auto& ev : p->ev_pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-    for (auto& ev : p->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    DeviceGuard dg(p->model->device);
     delete p;
 }
 size_t wt_plan_workspace_bytes(const wt_plan* p) { return p ? p->ws_bytes : 0; }
@@ -204,15 +207,19 @@ int wt_plan_buffer_name(const wt_plan* p, int32_t index, const char** name) {
     return WT_OK;
 }
 
-// Consumes the failure bits that earlier calls on the plan left in its host-visible word (the plan's lock is held).
-// After a lost-co-residency report the plan runs the LSTM one launch per step from now on, and a recorded graph (it
-// holds the persistent launch) is dropped.
+// Consumes the failure bits that earlier calls left behind (the plan's lock is held): those of this plan's own word
+// and those of the MODEL's word, into which every plan's guard step reports as well, so that a caller who never uses a plan
+// twice (one new length per file) still meets the error on its next call.  After a lost-co-residency report every plan
+// of the model runs the LSTM one launch per step from now on (wt_model::persist_ok), and a recorded graph that holds a
+// persistent launch is dropped.
 static unsigned consume_status(const wt_plan* p) {
-    if (!p->status_host) return 0;
-    const unsigned bits = __atomic_exchange_n(p->status_host, 0u, __ATOMIC_ACQUIRE);
-    if ((bits & WT_STATUS_LSTM) && p->persist_ok) {
-        p->persist_ok = false;
-        if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+    const wt_model* M = p->model;
+    unsigned bits = p->status_host ? __atomic_exchange_n(p->status_host, 0u, __ATOMIC_ACQUIRE) : 0u;
+    if (M->status_host) bits |= __atomic_exchange_n(M->status_host, 0u, __ATOMIC_ACQUIRE);
+    if (bits & WT_STATUS_LSTM) M->persist_ok.store(false);
+    if (p->graph_exec && p->graph_persist && !M->persist_ok.load()) {
+        (void)hipGraphExecDestroy(p->graph_exec);
+        p->graph_exec = nullptr; p->graph_persist = false;
         p->last_key = wt_plan::GraphKey{};
     }
     return bits;
@@ -225,11 +232,11 @@ static int run_plan(const wt_plan* p, const RunCtx& c) {
     if (!dg.ok) { set_error("hipSetDevice failed"); return WT_ERR_HIP; }
     if (const unsigned bits = consume_status(p)) {
         if (bits & WT_STATUS_LSTM) {
-            set_error("an earlier persistent LSTM launch on this plan lost co-residency (a step barrier timed out); that call's "
-                      "outputs were overwritten (codes = -1, NaN); the plan now runs the LSTM one launch per step: repeat the call");
+            set_error("an earlier persistent LSTM launch of this model lost co-residency (a step barrier timed out); that call's "
+                      "outputs were overwritten (codes = -1, NaN); the model's plans now run the LSTM one launch per step: repeat the call");
             return WT_ERR_LSTM_SYNC;
         }
-        set_error("an earlier call on this plan met a value outside the f16 range of the split-f16 (S32) form (|v| >= 65504); "
+        set_error("an earlier call on this model met a value outside the f16 range of the split-f16 (S32) form (|v| >= 65504); "
                   "that call's outputs were overwritten (codes = -1, NaN); re-plan with WT_PLAN_FLAG_FP32_GEMM and repeat the call");
         return WT_ERR_RANGE;
     }
@@ -272,6 +279,7 @@ static int run_plan_locked(const wt_plan* p, const RunCtx& c) {
                 if (ie != hipSuccess) { p->graph_exec = nullptr; p->graph_failed = true; (void)hipGetLastError(); }
                 else {
                     p->graph_key = key;
+                    p->graph_persist = p->uses_persist;       // recorded while wt_model::persist_ok held (checked on entry)
                     WT_HIP_CHECK(hipGraphLaunch(p->graph_exec, c.stream));
                     ++p->graph_replays;
                     return WT_OK;
@@ -429,15 +437,12 @@ int wt_linear(const float* x, const float* w, const float* bias, float* y, int64
     if (!f16x3) return launch_gemm(a, PRO_NONE, EPI_BIAS, s);
     if (!workspace) { set_error("wt_linear: the f16x3 modes need a workspace"); return WT_ERR_INVALID; }
     char* hi = static_cast<char*>(workspace);
-    if (f16x3 == 1) {
-        if (int rc = launch_split_f16x2(w, hi, hi + (size_t)N * K * 2, (long)N * K, s)) return rc;
-        a.W_hi = hi; a.w_lo_off = (long)N * K;
-        return launch_gemm16(a, PRO_NONE, EPI_BIAS, s);
-    }
+    if (f16x3 == 1) { set_error("wt_linear: mode 1 (the in-loop split kernel of round 1) was removed; use 2, 3 or 4"); return WT_ERR_INVALID; }
     char* xs = hi + (size_t)N * K * 4;
     if (int rc = split_pair(w, (long)N * K, x, (long)M * K, hi, xs, xs + (size_t)M * K * 4, a, s)) return rc;
     // timing-experiment builds (WT_GEMM16S_DBG: tools/gemm16s_bench.py) leave their clock stamps behind the scales
     a.dbg_stamps = reinterpret_cast<unsigned long long*>(xs + (size_t)M * K * 4 + 256);
+    if (f16x3 == 4) return launch_gemm16s(a, EPI_BIAS_GELU, OUT_S32, s);      // ConvNeXt pwconv1: exact-erf GELU epilogue, S32 out
     return launch_gemm16s(a, EPI_BIAS, f16x3 == 3 ? 1 : 0, s);
 }
 

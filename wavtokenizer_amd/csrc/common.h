@@ -150,8 +150,7 @@ struct GemmArgs {
     // W
     const float* W = nullptr;
     long w_rstride = 0;
-    const void* W_hi = nullptr;    // gemm16 only: f16 hi array [N][K]; the lo array starts w_lo_off halves later
-    long w_lo_off = 0;
+    const void* W_hi = nullptr;    // gemm16s: the S32 copy of W (same strides as the fp32 array)
     const float* bias = nullptr;
     int M = 0, N = 0, K = 0;
     // C
@@ -188,9 +187,6 @@ struct GemmArgs {
 
 int gemm_vq_parts(int N);   // partial (val, idx) slots per row written by EPI_ARGMAX
 int launch_gemm(const GemmArgs& a, int pro, int epi, hipStream_t s);
-int launch_gemm16(const GemmArgs& a, int pro, int epi, hipStream_t s);
-int gemm16_vq_parts(int N);
-int launch_split_f16x2(const float* w, void* hi, void* lo, long n, hipStream_t s);   // weights -> f16 (hi, lo) arrays (gemm16.hip)
 // gemm16s.hip: both operands pre-split in the S32 layout (128-byte groups [32 x f16 hi | 32 x f16 lo], same
 // footprint and strides as the fp32 array); a.A / a.W_hi point at S32 data, out_s32 selects an S32 C
 int launch_gemm16s(const GemmArgs& a, int epi, int out, hipStream_t s);     // out: Out16s
@@ -226,8 +222,8 @@ int launch_codes_to_features(const int64_t* codes, const float* embed, int K, in
 // buffer fill as a kernel (hipMemsetAsync nodes misbehave under hipGraph replay: ops.hip); 16-byte aligned pointer and size
 int launch_fill_u32(void* p, unsigned value, size_t n_bytes, hipStream_t s);
 // last step of every plan: on a non-zero status word poison the outputs (codes = -1, floats = NaN) and publish the bits
-int launch_plan_guard(const unsigned* status, unsigned* host_status, int64_t* codes, long n_codes, float* f0, long n0,
-                      float* f1, long n1, float* f2, long n2, hipStream_t s);
+int launch_plan_guard(const unsigned* status, unsigned* host_status, unsigned* model_status, int64_t* codes, long n_codes,
+                      float* f0, long n0, float* f1, long n1, float* f2, long n2, hipStream_t s);
 struct LstmArgs {
     const float* xg0;     // [L][B][4H] (time-major) layer-0 input projection (+ both biases), packed gate order
     const float* W0;      // W_hh_l0, per 16 packed gate rows: [H/16][64 lanes][4] (ops.hip lstm_step_kernel)

@@ -1,8 +1,8 @@
 // Split-f16 GEMM on PRE-SPLIT operands, staged global -> LDS by LDS-DMA (buffer_load ... lds).
 //
-// Same arithmetic as gemm16.hip (x = hi + lo * 2^-11, three v_mfma_f32_32x32x16_f16 per 16-deep step into a main
-// and a correction accumulator: fp32-equivalent products), but both operands arrive already split, in the
-// "S32" layout: every run of 32 consecutive fp32 elements of a row becomes one 128-byte group
+// Arithmetic: every fp32 operand x is carried as two f16 numbers, x = hi + lo * 2^-11, and a product is formed by three
+// f16 MFMAs into a main and a correction fp32 accumulator (hi.hi, then hi.lo + lo.hi scaled by 2^-11): fp32-equivalent
+// products.  Both operands arrive already split, in the "S32" layout: every run of 32 consecutive fp32 elements of a row becomes one 128-byte group
 //      [32 x f16 hi | 32 x f16 lo]
 // so an S32 array has exactly the footprint and the row strides of the fp32 array it stands for, element e of a
 // row starts at byte (e & ~31) * 4 + (e & 31) * 2, and one K step (32 deep) of one row is one full 128-byte line.
@@ -119,8 +119,8 @@ __device__ __forceinline__ void wait_vm_lgkm() {
 #ifndef WT_GEMM16S_MF
 #define WT_GEMM16S_MF 1          // MFMA shape of every instantiation (0: 32x32x16, for A/B timing builds; 1: 16x16x32)
 #endif
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int EPI, int OUT, int DBG = 0, int MF = WT_GEMM16S_MF>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm16s_kernel(const GemmArgs p) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int EPI, int OUT, int DBG = 0, int MF = WT_GEMM16S_MF, int WPS = 2>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(const GemmArgs p) {
     constexpr int dbg = DBG;
     constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -771,7 +771,7 @@ int launch_pow2_scales(const float* a, long na, const float* b, long nb, unsigne
 }
 
 // ---------------------------------------------------------------------------------- host side
-template <int BM, int BN, int WMs, int WNs, int NSTAGE, int EPI, int OUT>
+template <int BM, int BN, int WMs, int WNs, int NSTAGE, int EPI, int OUT, int WPS = 2>
 static int launch16s_one(const GemmArgs& a, hipStream_t s) {
     static PerDeviceOnce attr_once;
     constexpr size_t stage_bytes = (size_t)NSTAGE * (BM + BN) * 128;
@@ -782,23 +782,23 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
     static_assert(stage_bytes + 2 * BM * sizeof(unsigned) <= smem_cap, "LDS budget");
     if (smem > smem_cap) { set_error("gemm16s: too many taps for this tile's LDS budget"); return -1; }
     using kern_t = void (*)(const GemmArgs);
-    kern_t kern = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT>;
+    kern_t kern = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 0, WT_GEMM16S_MF, WPS>;
     // the timing-experiment builds exist for the tile the ConvNeXt GEMMs run on (tools/gemm16s_bench.py dbg): the masks of
     // the ablation ladder, each also with the clock stamps (+1024)
-    constexpr bool has_dbg = BM == 128 && BN == 192 && WMs == 4 && NSTAGE == 3 && ((EPI == EPI_BIAS && OUT == OUT_F32) || (EPI == EPI_BIAS_GELU && OUT == OUT_S32));
+    constexpr bool has_dbg = BM == 128 && BN == 192 && (WMs == 4 || WPS == 1) && NSTAGE == 3 && ((EPI == EPI_BIAS && OUT == OUT_F32) || (EPI == EPI_BIAS_GELU && OUT == OUT_S32));
     int dbg_req = 0;
     if (const char* e = getenv("WT_GEMM16S_DBG")) dbg_req = atoi(e);
     kern_t dbg_kerns[8] = {};
     static constexpr int dbg_masks[8] = {1024, 1024 + 4, 1024 + 5, 1024 + 13, 1024 + 45, 1024 + 61, 1024 + 64, 1024 + 21};
     if constexpr (has_dbg) {
-        dbg_kerns[0] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024>;
-        dbg_kerns[1] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024 + 4>;
-        dbg_kerns[2] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024 + 5>;
-        dbg_kerns[3] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024 + 13>;
-        dbg_kerns[4] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024 + 45>;
-        dbg_kerns[5] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024 + 61>;
-        dbg_kerns[6] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024 + 64>;
-        dbg_kerns[7] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024 + 21>;
+        dbg_kerns[0] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024, WT_GEMM16S_MF, WPS>;
+        dbg_kerns[1] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024 + 4, WT_GEMM16S_MF, WPS>;
+        dbg_kerns[2] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024 + 5, WT_GEMM16S_MF, WPS>;
+        dbg_kerns[3] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024 + 13, WT_GEMM16S_MF, WPS>;
+        dbg_kerns[4] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024 + 45, WT_GEMM16S_MF, WPS>;
+        dbg_kerns[5] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024 + 61, WT_GEMM16S_MF, WPS>;
+        dbg_kerns[6] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024 + 64, WT_GEMM16S_MF, WPS>;
+        dbg_kerns[7] = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 1024 + 21, WT_GEMM16S_MF, WPS>;
         if (dbg_req) {
             kern = nullptr;
             for (int i = 0; i < 8; ++i) if (dbg_masks[i] == (dbg_req | 1024)) kern = dbg_kerns[i];
@@ -806,7 +806,7 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
         }
     }
     if (int rc = attr_once.run([&]() -> int {
-        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT>),
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 0, WT_GEMM16S_MF, WPS>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max));
         for (int i = 0; i < 8; ++i)
             if (dbg_kerns[i]) WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dbg_kerns[i]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max));
@@ -817,7 +817,7 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
     // Persistent launch: one workgroup per slot (256 CUs x resident workgroups per CU), each walking tiles
     // b, b + G, ... with its loader streaming across the seams.  The slot count must stay a multiple of 8 so that a
     // workgroup's tiles stay on its XCD, and K must be deep enough for the table hand-over (see the kernel).
-    const int per_cu = (WMs * WNs <= 4 && smem * 2 <= smem_cap) ? 2 : 1;
+    const int per_cu = (WPS >= 2 && WMs * WNs <= 4 && smem * 2 <= smem_cap) ? 2 : 1;
     int G = (256 * per_cu / a.nz) & ~7;
     const char* np = getenv("WT_GEMM16S_NONPERSISTENT");
     if (G < 8 || ntiles <= G || a.K / SBK < NSTAGE + 1 || (np && np[0] == '1')) G = ntiles;
@@ -881,6 +881,7 @@ static int launch16s_tiled(const GemmArgs& a, hipStream_t s) {
             case 7: return launch16s_one<256, 128, 4, 2, 3, EPI, OUT>(a, s);
             case 8: return launch16s_one<128, 32, 4, 1, 3, EPI, OUT>(a, s);
             case 9: return launch16s_one<128, 64, 4, 1, 3, EPI, OUT>(a, s);
+            case 10: return launch16s_one<128, 192, 2, 2, 3, EPI, OUT, 1>(a, s);     // 4 waves, one per SIMD, 512 registers
             default: break;
         }
         if (a.N <= 64) return launch16s_one<256, 64, 8, 1, 3, EPI, OUT>(a, s);      // narrow outputs (down conv 1)
@@ -903,7 +904,7 @@ static int launch16s_tiled(const GemmArgs& a, hipStream_t s) {
 
 int gemm16s_vq_parts(int N) { return ((N + 191) / 192) * 2; }      // (column tiles of 192) x (2 wave columns)
 
-// Contract of launch_gemm16 with both operands in S32: a.A = S32 activations (same strides as the fp32 array),
+// Contract: a.A = S32 activations (same strides as the fp32 array),
 // a.W_hi = S32 weights [N][K]; out_s32 selects an S32 C (c_rstride in fp32 elements either way).
 int launch_gemm16s(const GemmArgs& a_in, int epi, int out, hipStream_t s) {
     const bool out_s32 = out != OUT_F32;        // some S32 array is written: whole 32-column groups

@@ -5,6 +5,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cmath>
 #include <cstring>
@@ -65,12 +66,8 @@ struct wt_model {
     std::vector<void*> allocs;
     std::vector<size_t> alloc_bytes;     // size of each allocation (the packed image stores them in this order)
     int64_t weight_bytes = 0;
-    // f16 (hi, lo) copies of the weight matrices the split-precision GEMM (gemm16.hip) reads, keyed by the
-    // fp32 device pointer the plans already use; `lo_off` = elements between the hi and the lo array
-    struct Split16 { void* hi; long lo_off; };
-    std::map<const float*, Split16> split16;
     // S32 copies (gemm16s.hip: 128-byte groups [32 x f16 hi | 32 x f16 lo], same footprint as fp32) of the weights
-    // whose GEMMs take pre-split activations, keyed the same way
+    // whose GEMMs take pre-split activations, keyed by the fp32 device pointer the plans already use
     std::map<const float*, void*> s32;
     std::map<const float*, bool> s32_tap_pair;       // that S32 copy holds its taps in paired order (GemmArgs::tap_pair)
     // encoder
@@ -107,6 +104,13 @@ struct wt_model {
     // host-mapped word for wt_codes_to_features: set by the kernel when it meets an index outside the codebook
     unsigned* bad_codes_host = nullptr;
     unsigned* bad_codes_dev = nullptr;
+    // Model-level call status: every plan's guard step ORs the failure bits of its call into this host-mapped word too, and
+    // the NEXT call on ANY plan of the model consumes it (a file-by-file caller meets a new length, hence a new plan, per
+    // file: a per-plan word alone would never be looked at again).  The consequences are sticky for the model:
+    // persist_ok = false after a lost-co-residency report sends every plan's LSTM to the launch-per-step kernel.
+    unsigned* status_host = nullptr;
+    unsigned* status_dev = nullptr;
+    mutable std::atomic<bool> persist_ok{true};
 };
 
 namespace wt {
@@ -180,8 +184,8 @@ struct wt_plan {
     unsigned* status_host = nullptr;
     unsigned* status_dev = nullptr;       // device address of status_host
     int ctl = -1;                         // buffer id of the control block
-    bool uses_persist = false;            // some step launches lstm_persist_kernel
-    mutable bool persist_ok = true;       // false after a lost-co-residency report: the LSTM then runs one launch per step
+    bool uses_persist = false;            // some step launches lstm_persist_kernel (while wt_model::persist_ok holds)
+    mutable bool graph_persist = false;   // the recorded graph holds a persistent LSTM launch
     // one host call at a time per plan (graph capture state, timing events and persist_ok are per plan)
     mutable std::mutex mu;
     // WT_PLAN_FLAG_GRAPH: the launch sequence of a call, captured once and replayed with hipGraphLaunch while the
@@ -198,6 +202,16 @@ struct wt_plan {
     mutable hipGraphExec_t graph_exec = nullptr;
     mutable hipStream_t cap_stream = nullptr;
     mutable long graph_replays = 0;
+
+    wt_plan() = default;
+    wt_plan(const wt_plan&) = delete;
+    ~wt_plan() {
+        if (status_host) (void)hipHostFree(status_host);
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        if (cap_stream) (void)hipStreamDestroy(cap_stream);
+        for (auto& ev : ev_pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+        for (auto& ev : ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    }
 
     int buf(const std::string& name, size_t numel, int fmt = wt::BUF_F32) {
         wt::BufSpec b;
@@ -260,6 +274,7 @@ size_t model_export_bytes(const wt_model* M);
 int model_export(const wt_model* M, void* buf, size_t n);
 int model_import(wt_model* M, const void* buf, size_t n);        // M->device set; allocates and uploads
 int packed_info(const void* buf, size_t n, wt_arch* arch, int32_t* version, uint64_t* arch_hash);
+int packed_verify(const void* buf, size_t n);                    // header + bounds + content hash; needs no GPU
 // plan.cpp
 struct SConvGeom { int pl, pr_total, Tout, Tp; };
 SConvGeom sconv_geom(long T, int k, int stride, int dil);

@@ -825,12 +825,14 @@ int launch_istft_ola(const float* parts, const float* win, const float* wsq, flo
 // failed call can never hand out plausible-looking data, and the bits are OR-ed into the plan's host-visible word,
 // where the next host call on the plan (or wt_plan_status) finds them.
 __global__ __launch_bounds__(256) void plan_guard_kernel(const unsigned* __restrict__ status, unsigned* host_status,
-                                                         int64_t* codes, long n_codes, float* f0, long n0, float* f1, long n1,
+                                                         unsigned* model_status, int64_t* codes, long n_codes, float* f0, long n0, float* f1, long n1,
                                                          float* f2, long n2) {
     const unsigned st = *status;
     if (st == 0u) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && host_status)
-        __hip_atomic_fetch_or(host_status, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (host_status) __hip_atomic_fetch_or(host_status, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (model_status) __hip_atomic_fetch_or(model_status, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     const long step = (long)gridDim.x * blockDim.x, i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const float qnan = __builtin_nanf("");
     if (codes) for (long i = i0; i < n_codes; i += step) codes[i] = -1;
@@ -857,9 +859,9 @@ int launch_fill_u32(void* p, unsigned value, size_t n_bytes, hipStream_t s) {
     return 0;
 }
 
-int launch_plan_guard(const unsigned* status, unsigned* host_status, int64_t* codes, long n_codes, float* f0, long n0,
-                      float* f1, long n1, float* f2, long n2, hipStream_t s) {
-    hipLaunchKernelGGL(plan_guard_kernel, dim3(256), dim3(256), 0, s, status, host_status, codes, n_codes, f0, n0, f1, n1, f2, n2);
+int launch_plan_guard(const unsigned* status, unsigned* host_status, unsigned* model_status, int64_t* codes, long n_codes,
+                      float* f0, long n0, float* f1, long n1, float* f2, long n2, hipStream_t s) {
+    hipLaunchKernelGGL(plan_guard_kernel, dim3(256), dim3(256), 0, s, status, host_status, model_status, codes, n_codes, f0, n0, f1, n1, f2, n2);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1028,7 +1030,7 @@ typedef _Float16 f16x8l __attribute__((ext_vector_type(8)));
 
 // F16 = false: v_mfma_f32_16x16x4_f32 on the fp32 state (exact fp32 multiply-add chain).
 // F16 = true : the recurrent product on the f16 matrix pipe with fp32-equivalent products (x = hi + lo * 2^-11,
-//              three v_mfma_f32_16x16x32_f16 per 32-deep block, gemm16.hip): the state is stored pre-split, K-major,
+//              three v_mfma_f32_16x16x32_f16 per 32-deep block, gemm16s.hip): the state is stored pre-split, K-major,
 //              16 bytes per (k, clip quad) = [hi of 4 clips | lo of 4 clips] (same pitch and addresses as the fp32
 //              state), so a lane's load is the same 16 bytes; its 8 loads of a 32-deep block are re-packed in
 //              registers into the A operands of the four clip groups, and the weights arrive packed per lane as

@@ -12,28 +12,9 @@ static bool plan_fp32(const wt_plan* P) {
 static bool plan_unfused(const wt_plan* P) { return P->flags & WT_PLAN_FLAG_UNFUSED; }
 static bool plan_s32(const wt_plan* P) { return !plan_unfused(P) && !plan_fp32(P); }
 
-// Dense layers run on the split-f16 kernel (fp32-equivalent, gemm16.hip) when the weight has a split copy and
-// the shape/epilogue is covered; everything else (ELU prologue, argmax, head, activation x activation
-// products, K % 32 != 0, WT_PLAN_FLAG_FP32_GEMM) on the fp32 MFMA chain of gemm.hip.
-static bool gemm16_covers(const wt_plan* P, const GemmArgs& a, int pro, int epi) {
-    if (plan_fp32(P)) return false;
-    if (a.N < 64 || a.K % 32 || a.Cin % 8 || (a.taps > 1 && a.Cin % 32) || a.w_rstride % 8 || a.zW % 8) return false;
-    const bool ok_pair = (pro == PRO_NONE && (epi == EPI_BIAS || epi == EPI_BIAS_RES || epi == EPI_BIAS_GELU ||
-                                               epi == EPI_BIAS_GAMMA_RES || epi == EPI_HEAD || epi == EPI_ARGMAX)) ||
-                         (pro == PRO_ELU && (epi == EPI_BIAS || epi == EPI_BIAS_RES || epi == EPI_BIAS_RES_ELU));
-    // a weight that needed a per-tensor scale for its S32 copy is outside what the unscaled f16x2 split covers
-    return ok_pair && P->model->split16.count(a.W) != 0 && P->model->s32_acc_scale.count(a.W) == 0;
-}
-static int gemm_auto(const wt_plan* P, const GemmArgs& a, int pro, int epi, hipStream_t s) {
-    if (gemm16_covers(P, a, pro, epi)) {
-        const auto& sp = P->model->split16.at(a.W);
-        GemmArgs b = a;
-        b.W_hi = sp.hi;
-        b.w_lo_off = sp.lo_off;
-        return launch_gemm16(b, pro, epi, s);
-    }
-    return launch_gemm(a, pro, epi, s);
-}
+// Everything the S32 chain does not cover (the fp32 plans: WT_PLAN_FLAG_FP32_GEMM, the unfused debug twin, a model whose
+// weights do not fit the split-f16 range) runs on the fp32 MFMA chain of gemm.hip
+static int gemm_auto(const wt_plan*, const GemmArgs& a, int pro, int epi, hipStream_t s) { return launch_gemm(a, pro, epi, s); }
 
 // Both operands pre-split (S32): the activations were written in S32 by their producer, the weight has an S32 copy
 static int gemm_s32(const wt_plan* P, const GemmArgs& a, int epi, int out, hipStream_t s) {
@@ -170,7 +151,7 @@ static int plan_lstm(wt_plan* P, const LstmW& w, int B, int L, int H, int xin, c
     const size_t hxn = lstm_persist_hx_bytes() / sizeof(float), ctn = lstm_persist_ctl_bytes() / sizeof(float);
     const int hx = persist ? P->buf(name + ".hx", hxn + ctn) : -1;
     P->step({xin, xg, st, hx, y}, [=](const RunCtx& c) {
-        if (persist && P->persist_ok) {
+        if (persist && P->model->persist_ok.load()) {
             float* hb = P->ptr(c, hx);
             static const bool counter_form = [] { const char* e = getenv("WT_LSTM_PERSIST"); return e && e[0] == '2'; }();
             if (int rc = launch_fill_u32(hb, counter_form ? 0u : 0xFFFFFFFFu, (hxn + ctn) * sizeof(float), c.stream)) return rc;
@@ -352,8 +333,7 @@ int build_encode(wt_plan* P) {
     GemmArgs av = linear_args(M->embed, nullptr, (long)B * L, bins, 512);
     // the argmax epilogue leaves one (value, index) candidate per wave column slab; their number depends on
     // which kernel the distance GEMM runs on
-    const int np = tail_s32 ? gemm16s_vq_parts(bins)
-                            : (gemm16_covers(P, av, PRO_NONE, EPI_ARGMAX) ? gemm16_vq_parts(bins) : gemm_vq_parts(bins));
+    const int np = tail_s32 ? gemm16s_vq_parts(bins) : gemm_vq_parts(bins);
     const int xx = P->buf("vq.xx", (size_t)B * L);
     const int pv = P->buf("vq.pval", (size_t)B * L * np);
     const int pi = P->buf("vq.pidx", (size_t)B * L * np);
@@ -783,8 +763,8 @@ void plan_end(wt_plan* P) {
         else if (kind == WT_PLAN_UNIT_LSTM) { n0 = B * L * 512; f1 = nullptr; }
         else if (kind == WT_PLAN_HEAD) { n0 = B * wave_samples(M, L); f1 = nullptr; }
         else { n0 = B * L * hop; f1 = nullptr; }
-        return launch_plan_guard(reinterpret_cast<const unsigned*>(P->ptr(c, ctl)), P->status_dev, codes, nc, c.out_f, n0, f1, n1,
-                                 nullptr, 0, c.stream);
+        return launch_plan_guard(reinterpret_cast<const unsigned*>(P->ptr(c, ctl)), P->status_dev, M->status_dev, codes, nc, c.out_f, n0,
+                                 f1, n1, nullptr, 0, c.stream);
     }, 1, "guard");
 }
 

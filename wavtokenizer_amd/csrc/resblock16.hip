@@ -4,7 +4,7 @@
 //
 // Same fusion as resblock.hip (x tile with its k=3 halo in LDS, conv1 frame-local, weights resident in LDS, persistent
 // workgroups), but every contraction runs as split-f16 (x = hi + lo * 2^-11, three f16 MFMAs per K step, main + correction
-// accumulator: gemm16.hip) instead of v_mfma_f32_32x32x2_f32.  The split is done ONCE per element when the tile is filled
+// accumulator: gemm16s.hip) instead of v_mfma_f32_32x32x2_f32.  The split is done ONCE per element when the tile is filled
 // (ELU too, not once per tap), the LDS images hold rows of [hi | lo] f16 with XOR-swizzled 16-byte chunks so every
 // ds_read_b128 fragment read is conflict-free, and the weights are the MFMA's A operand: the accumulator comes out with the
 // frame on the lane and 4-channel runs in the registers, so the epilogue stores 16 bytes (fp32) or 8 + 8 bytes (S32) per lane.

@@ -412,18 +412,6 @@ int build_model(wt_model* M, TensorMap& tm) {
     return 0;
 }
 
-static int add_split(wt_model* M, const float* w, long n) {
-    if (!w || n <= 0 || (n % 8)) return 0;
-    void* d = nullptr;
-    WT_HIP_CHECK(hipMalloc(&d, (size_t)n * 4));
-    M->allocs.push_back(d);
-    M->alloc_bytes.push_back((size_t)n * 4);
-    M->weight_bytes += n * 4;
-    if (int rc = launch_split_f16x2(w, d, static_cast<char*>(d) + (size_t)n * 2, n, nullptr)) return rc;
-    M->split16[w] = {d, n};
-    return 0;
-}
-
 // S32 copy of a GEMM weight.  hi = f16(w) covers |w| < 65504 with fp32-equivalent products only while the tensor's
 // largest magnitude is not far from 1 (x = hi + lo * 2^-11 has an absolute floor of 2^-36), so a tensor whose maximum
 // lies outside [2^-6, 2^12] is stored as w * 2^e (maximum brought into [1, 2)) and its GEMMs multiply their
@@ -467,7 +455,6 @@ static int add_s32(wt_model* M, const float* w, long n, bool* split_ok = nullptr
 int build_splits(wt_model* M) {
     const wt_arch& a = M->arch;
     const int D = a.dim, I = a.intermediate_dim;
-    auto conv = [&](const ConvW& c) { return add_split(M, c.w, (long)c.cout * c.k * c.cin); };
     auto conv32 = [&](const ConvW& c) { return (c.cin % 32) ? 0 : add_s32(M, c.w, (long)c.cout * c.k * c.cin); };
     // the SEANetDecoder's weights are all zeros -> NaN after the weight-norm fold when a checkpoint without them was
     // loaded into the full module tree: they only decide how the SEANetDecoder plan runs
@@ -527,38 +514,6 @@ int build_splits(wt_model* M) {
             if (st.cat.w) if (int rc = conv32sd(st.cat)) return rc;
         }
     }
-    for (const ResStage& st : M->stages) {
-        if (int rc = conv(st.down)) return rc;
-        if (int rc = conv(st.sc)) return rc;
-        if (int rc = conv(st.c3)) return rc;
-        if (int rc = conv(st.c1)) return rc;
-    }
-    if (int rc = add_split(M, M->embed, (long)a.vq_bins * 512)) return rc;
-    if (int rc = add_split(M, M->head_W, 2L * M->Kb * D)) return rc;
-    if (int rc = conv(M->enc_final)) return rc;
-    if (int rc = add_split(M, M->enc_lstm.Wih0, 4L * M->H * M->H)) return rc;
-    if (int rc = conv(M->bb_embed)) return rc;
-    for (int i = 0; i < 4; ++i) {
-        if (int rc = conv(M->res[i].c1)) return rc;
-        if (int rc = conv(M->res[i].c2)) return rc;
-    }
-    if (int rc = add_split(M, M->at_Wqk, 2L * D * D)) return rc;
-    if (int rc = add_split(M, M->at_Wp, (long)D * D)) return rc;
-    for (const CnxBlock& c : M->cnx) {
-        if (int rc = add_split(M, c.W1, (long)I * D)) return rc;
-        if (int rc = add_split(M, c.W2, (long)D * I)) return rc;
-    }
-    if (int rc = add_split(M, M->istft_W, 4L * M->Kq * M->Kq)) return rc;
-    if (M->has_seadec) {
-        if (int rc = conv(M->sd_first)) return rc;
-        if (int rc = add_split(M, M->sd_lstm.Wih0, 4L * M->H * M->H)) return rc;
-        for (const SeaDecStage& st : M->sd_stages) {
-            if (st.tr_wp) if (int rc = add_split(M, st.tr_wp, (long)st.r * st.cout * 2 * st.cin)) return rc;
-            if (int rc = conv(st.sc)) return rc;
-            if (int rc = conv(st.c3)) return rc;
-            if (int rc = conv(st.c1)) return rc;
-        }
-    }
     WT_HIP_CHECK(hipDeviceSynchronize());
     return 0;
 }
@@ -571,7 +526,7 @@ int build_splits(wt_model* M) {
 // header (magic, version, the wt_arch and a hash of it) and the model struct with every pointer written as
 // (allocation index).  Loading it is allocate + upload + fix up pointers: nothing is folded, packed or split again.
 static constexpr uint32_t PACK_MAGIC = 0x4b505457u;     // "WTPK"
-static constexpr int32_t PACK_VERSION = 3;
+static constexpr int32_t PACK_VERSION = 4;
 
 static uint64_t arch_hash_of(const wt_arch& a) {        // FNV-1a over the architecture struct and the layout version
     uint64_t h = 1469598103934665603ull;
@@ -589,9 +544,17 @@ struct Archive {
     bool ok = true;
     const std::map<const void*, int>* index = nullptr;      // saving: allocation base -> index
     const std::vector<void*>* allocs = nullptr;             // loading: index -> allocation base
+    const std::vector<size_t>* alloc_bytes = nullptr;       // loading: index -> allocation size (pointer offsets are checked)
     void raw(void* p, size_t bytes) {
         if (saving) { const char* c = static_cast<const char*>(p); out->insert(out->end(), c, c + bytes); }
-        else { if (pos + bytes > n) { ok = false; return; } std::memcpy(p, in + pos, bytes); pos += bytes; }
+        else { if (!ok || bytes > n - pos) { ok = false; std::memset(p, 0, bytes); return; } std::memcpy(p, in + pos, bytes); pos += bytes; }
+    }
+    // an element count read from the file: bounded before anything is resized by it
+    int32_t count(size_t have, int32_t limit) {
+        int32_t c = (int32_t)have;
+        pod(c);
+        if (!saving && (c < 0 || c > limit)) { ok = false; c = 0; }
+        return c;
     }
     template <class T> void pod(T& v) { raw(&v, sizeof(T)); }
     template <class T> void ptr(T*& p) {       // a device pointer = (allocation index, byte offset); -1 = null
@@ -605,7 +568,7 @@ struct Archive {
         pod(idx); pod(off);
         if (!saving) {
             if (idx < 0) p = nullptr;
-            else if (idx >= (int)allocs->size()) { ok = false; p = nullptr; }
+            else if (!ok || idx >= (int)allocs->size() || off < 0 || (size_t)off >= (*alloc_bytes)[idx]) { ok = false; p = nullptr; }
             else p = reinterpret_cast<T*>(static_cast<char*>((*allocs)[idx]) + off);
         }
     }
@@ -615,25 +578,24 @@ struct Archive {
 
 static void archive_model(Archive& ar, wt_model* M) {
     ar.pod(M->hop); ar.pod(M->H); ar.pod(M->weight_bytes); ar.pod(M->s32_ok); ar.pod(M->sd_s32_ok); ar.pod(M->w_amax);
-    int32_t n = (int32_t)M->enc_ratios.size();
-    ar.pod(n);
+    int32_t n = ar.count(M->enc_ratios.size(), 8);
     M->enc_ratios.resize(n);
     for (int& r : M->enc_ratios) ar.pod(r);
     ar.ptr(M->e0_w); ar.ptr(M->e0_b); ar.pod(M->e0_k); ar.pod(M->e0_c);
-    n = (int32_t)M->stages.size(); ar.pod(n); M->stages.resize(n);
+    n = ar.count(M->stages.size(), 8); M->stages.resize(n);
     for (ResStage& st : M->stages) { ar.conv(st.c3); ar.conv(st.c1); ar.conv(st.sc); ar.conv(st.down); ar.conv(st.cat); ar.pod(st.C); ar.pod(st.r); }
     ar.lstm(M->enc_lstm); ar.conv(M->enc_final); ar.ptr(M->embed); ar.ptr(M->ee);
     ar.conv(M->bb_embed);
     for (PosRes& r : M->res) { ar.ptr(r.n1w); ar.ptr(r.n1b); ar.ptr(r.n2w); ar.ptr(r.n2b); ar.conv(r.c1); ar.conv(r.c2); }
     ar.ptr(M->at_nw); ar.ptr(M->at_nb); ar.ptr(M->at_Wqk); ar.ptr(M->at_bqk); ar.ptr(M->at_Wv); ar.ptr(M->at_bv); ar.ptr(M->at_Wp); ar.ptr(M->at_bp);
     ar.ptr(M->gn5w); ar.ptr(M->gn5b); ar.ptr(M->ada_s); ar.ptr(M->ada_h);
-    n = (int32_t)M->cnx.size(); ar.pod(n); M->cnx.resize(n);
+    n = ar.count(M->cnx.size(), 64); M->cnx.resize(n);
     for (CnxBlock& c : M->cnx) { ar.ptr(c.dw_w); ar.ptr(c.dw_b); ar.ptr(c.ada_s); ar.ptr(c.ada_h); ar.ptr(c.W1); ar.ptr(c.b1); ar.ptr(c.W2); ar.ptr(c.b2); ar.ptr(c.gamma); }
     ar.ptr(M->fln_w); ar.ptr(M->fln_b); ar.ptr(M->head_W); ar.ptr(M->head_b);
     ar.pod(M->Kb); ar.pod(M->Kq); ar.pod(M->bins_f); ar.pod(M->R);
     ar.ptr(M->istft_W); ar.ptr(M->wsq); ar.ptr(M->win);
     ar.pod(M->has_seadec); ar.conv(M->sd_first); ar.lstm(M->sd_lstm);
-    n = (int32_t)M->sd_stages.size(); ar.pod(n); M->sd_stages.resize(n);
+    n = ar.count(M->sd_stages.size(), 8); M->sd_stages.resize(n);
     for (SeaDecStage& st : M->sd_stages) {
         ar.ptr(st.tr_w); ar.ptr(st.tr_wp); ar.ptr(st.tr_b); ar.pod(st.cin); ar.pod(st.cout); ar.pod(st.k); ar.pod(st.r);
         ar.conv(st.c3); ar.conv(st.c1); ar.conv(st.sc); ar.conv(st.cat);
@@ -641,8 +603,7 @@ static void archive_model(Archive& ar, wt_model* M) {
     ar.ptr(M->sd_last_w); ar.ptr(M->sd_last_b);
     // the maps keyed by the fp32 weight pointer
     auto map_ptr = [&](auto& m, auto value_io) {
-        int32_t cnt = (int32_t)m.size();
-        ar.pod(cnt);
+        const int32_t cnt = ar.count(m.size(), 1 << 16);
         if (ar.saving) {
             // in allocation order, not in address order: the image of a model does not depend on where hipMalloc put it
             std::vector<const float*> keys;
@@ -654,7 +615,6 @@ static void archive_model(Archive& ar, wt_model* M) {
             for (int i = 0; i < cnt && ar.ok; ++i) { const float* k = nullptr; ar.ptr(k); auto& v = m[k]; value_io(v); }
         }
     };
-    map_ptr(M->split16, [&](wt_model::Split16& v) { ar.ptr(v.hi); ar.pod(v.lo_off); });
     map_ptr(M->s32, [&](void*& v) { ar.ptr(v); });
     map_ptr(M->s32_tap_pair, [&](bool& v) { ar.pod(v); });
     map_ptr(M->s32_acc_scale, [&](float& v) { ar.pod(v); });
@@ -666,7 +626,24 @@ struct PackHeader {
     wt_arch arch;
     uint64_t arch_hash;
     uint64_t n_allocs, struct_bytes, payload_bytes;
+    uint64_t body_hash;        // over the allocation table, the model section and the payload (everything behind the header)
 };
+
+// 64-bit hash of a byte range, four interleaved multiply-xor lanes over 8-byte words (a serial FNV over ~0.7 GB would
+// take longer than the upload itself); the tail bytes and the length go into lane 0
+static uint64_t body_hash_of(const char* p, size_t n) {
+    uint64_t h[4] = {0x9e3779b97f4a7c15ull, 0xc2b2ae3d27d4eb4full, 0x165667b19e3779f9ull, 0x27d4eb2f165667c5ull};
+    const uint64_t K = 0x100000001b3ull * 0x9e3779b1ull | 1ull;
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+        uint64_t w[4];
+        std::memcpy(w, p + i, 32);
+        for (int l = 0; l < 4; ++l) { h[l] = (h[l] ^ w[l]) * K; h[l] ^= h[l] >> 29; }
+    }
+    for (; i < n; ++i) { h[0] = (h[0] ^ (unsigned char)p[i]) * K; h[0] ^= h[0] >> 29; }
+    h[0] = (h[0] ^ (uint64_t)n) * K;
+    return (h[0] ^ (h[1] * 3) ^ (h[2] * 5) ^ (h[3] * 7)) * K;
+}
 
 size_t model_export_bytes(const wt_model* M) {
     size_t total = sizeof(PackHeader) + M->allocs.size() * sizeof(uint64_t) + (1u << 16);      // struct section: generous bound
@@ -694,7 +671,6 @@ int model_export(const wt_model* Mc, void* buf, size_t n) {
     if (pos > n) { set_error("wt_model_export: buffer too small (wt_model_export_bytes)"); return WT_ERR_INVALID; }
     char* o = static_cast<char*>(buf);
     std::memset(o, 0, payload0);
-    std::memcpy(o, &h, sizeof(h));
     for (size_t i = 0; i < M->allocs.size(); ++i) { uint64_t b = M->alloc_bytes[i]; std::memcpy(o + sizeof(h) + i * 8, &b, 8); }
     std::memcpy(o + sizeof(h) + M->allocs.size() * 8, st.data(), st.size());
     pos = payload0;
@@ -705,6 +681,8 @@ int model_export(const wt_model* Mc, void* buf, size_t n) {
         std::memset(o + pos + b, 0, padded - b);
         pos += padded;
     }
+    h.body_hash = body_hash_of(o + sizeof(h), pos - sizeof(h));
+    std::memcpy(o, &h, sizeof(h));
     return (int)0;
 }
 
@@ -718,15 +696,40 @@ int packed_info(const void* buf, size_t n, wt_arch* arch, int32_t* version, uint
     if (arch_hash) *arch_hash = h.arch_hash;
     if (h.version != PACK_VERSION) { set_error("packed image: layout version " + std::to_string(h.version) + ", this library reads " + std::to_string(PACK_VERSION)); return WT_ERR_INVALID; }
     if (h.arch_hash != arch_hash_of(h.arch)) { set_error("packed image: architecture hash mismatch (corrupt header)"); return WT_ERR_INVALID; }
-    const size_t head = sizeof(PackHeader) + h.n_allocs * 8 + h.struct_bytes;
-    if (h.n_allocs > (1u << 20) || head > n || (head + 255) / 256 * 256 + h.payload_bytes > n) { set_error("packed image: truncated"); return WT_ERR_INVALID; }
+    // every term is checked against what is left of the file before it is added: nothing here can wrap
+    size_t left = n - sizeof(PackHeader);
+    if (h.n_allocs > (1u << 16) || h.n_allocs * 8 > left) { set_error("packed image: truncated (allocation table)"); return WT_ERR_INVALID; }
+    left -= h.n_allocs * 8;
+    if (h.struct_bytes > (1u << 24) || h.struct_bytes > left) { set_error("packed image: truncated (model section)"); return WT_ERR_INVALID; }
+    const size_t head = sizeof(PackHeader) + h.n_allocs * 8 + h.struct_bytes, head_pad = (head + 255) / 256 * 256;
+    if (head_pad > n || h.payload_bytes > n - head_pad) { set_error("packed image: truncated (payload)"); return WT_ERR_INVALID; }
+    return WT_OK;
+}
+
+// full check of an image that needs no GPU: header, table and section bounds, and the hash of everything behind the header
+int packed_verify(const void* buf, size_t n) {
+    if (int rc = packed_info(buf, n, nullptr, nullptr, nullptr)) return rc;
+    PackHeader h;
+    std::memcpy(&h, buf, sizeof(h));
+    const char* in = static_cast<const char*>(buf);
+    const size_t head_pad = (sizeof(PackHeader) + h.n_allocs * 8 + h.struct_bytes + 255) / 256 * 256;
+    size_t pos = head_pad;
+    for (size_t i = 0; i < h.n_allocs; ++i) {
+        uint64_t b;
+        std::memcpy(&b, in + sizeof(h) + i * 8, 8);
+        if (b == 0 || b > n - pos || (b + 255) / 256 * 256 > n - pos) { set_error("packed image: allocation table does not fit the payload"); return WT_ERR_INVALID; }
+        pos += (b + 255) / 256 * 256;
+    }
+    if (pos - head_pad != h.payload_bytes) { set_error("packed image: allocation table and payload size disagree"); return WT_ERR_INVALID; }
+    if (body_hash_of(in + sizeof(h), pos - sizeof(h)) != h.body_hash) { set_error("packed image: content hash mismatch (corrupt file)"); return WT_ERR_INVALID; }
     return WT_OK;
 }
 
 int model_import(wt_model* M, const void* buf, size_t n) {
     PackHeader h;
-    if (int rc = packed_info(buf, n, &M->arch, nullptr, nullptr)) return rc;
+    if (int rc = packed_verify(buf, n)) return rc;
     std::memcpy(&h, buf, sizeof(h));
+    M->arch = h.arch;
     const char* in = static_cast<const char*>(buf);
     size_t pos = (sizeof(PackHeader) + h.n_allocs * 8 + h.struct_bytes + 255) / 256 * 256;
     for (size_t i = 0; i < h.n_allocs; ++i) {
@@ -742,7 +745,7 @@ int model_import(wt_model* M, const void* buf, size_t n) {
         pos += padded;
     }
     Archive ar;
-    ar.saving = false; ar.in = in + sizeof(h) + h.n_allocs * 8; ar.n = h.struct_bytes; ar.allocs = &M->allocs;
+    ar.saving = false; ar.in = in + sizeof(h) + h.n_allocs * 8; ar.n = h.struct_bytes; ar.allocs = &M->allocs; ar.alloc_bytes = &M->alloc_bytes;
     archive_model(ar, M);
     if (!ar.ok || ar.pos != ar.n) { set_error("packed image: model section does not match this library's layout"); return WT_ERR_INVALID; }
     return WT_OK;

@@ -274,7 +274,12 @@ class WavTokenizer(nn.Module):
         self._dirty = True
         self._plan_flags = 0
         self._strict = os.environ.get("WAVTOK_STRICT_STATUS", "0") == "1"
-        self._check_codes = os.environ.get("WAVTOK_CHECK_CODES", "1") == "1"   # codes_to_features raises on bad indices
+        # codes_to_features and indices outside the codebook (F.embedding raises IndexError, pretrained.py:236): "deferred"
+        # (default) raises on the NEXT call on this model or in check_status() without synchronising the stream, like the
+        # reference's CUDA F.embedding, whose device-side assert also surfaces later; "sync" synchronises after the gather
+        # and raises at once; "off" never looks.  The gathered features of a bad index are NaN in every mode.
+        self._check_codes = {"1": "deferred", "0": "off"}.get(os.environ.get("WAVTOK_CHECK_CODES", "deferred"),
+                                                              os.environ.get("WAVTOK_CHECK_CODES", "deferred"))
         self._bw_cache = None                # (tensor ref, version, index): bandwidth_id tensors living on the GPU
         # batches up to this many clips are replayed as one hipGraph per (shape) plan: they are bound by the host's
         # launch rate (about 100 launches per call), not by the GPU; 0 turns graphs off
@@ -324,25 +329,32 @@ class WavTokenizer(nn.Module):
         model.eval()
         return model
 
+    @staticmethod
+    def _best_checkpoints(folder: str, keep: int = 3) -> List[str]:
+        """File names of the `vocos_*` checkpoints to average: the reference ranks them by the six characters that
+        precede the extension (the validation loss printed into the name) as STRINGS and keeps every file whose tag is
+        among the `keep` smallest, in directory order (pretrained.py:122-138)."""
+        names = [n for n in os.listdir(folder) if n.startswith("vocos_")]
+        loss_tag = lambda n: n[-11:-5]
+        chosen = set(sorted(loss_tag(n) for n in names)[:keep])
+        return [n for n in names if loss_tag(n) in chosen]
+
     @classmethod
     def from_pretrained0911(cls, config_path: str, model_folder_path: str) -> "WavTokenizer":
-        """Average of the three `vocos_*` checkpoints with the lowest val loss in the file name
-        (pretrained.py:117-156)."""
+        """Mean of the best `vocos_*` checkpoints of a folder (pretrained.py:117-156): tensors are summed in directory
+        order and divided by the count, in their own dtype, exactly as the reference does."""
         model = cls.from_hparams0802(config_path)
-        models = os.listdir(model_folder_path)
-        val_loss = sorted(item[-11:-5] for item in models if item.startswith("vocos_"))[:3]
-        state_dicts = []
-        for item in models:
-            if not item.startswith("vocos_") or item[-11:-5] not in val_loss:
-                continue
-            state_dicts.append(cls._filter_state(cls._read_ckpt(model_folder_path + "/" + item)))
-        state_dict = {}
-        for kk in state_dicts[0].keys():
-            vv = state_dicts[0][kk]
-            for ss in state_dicts[1:]:
-                vv = vv + ss[kk]
-            state_dict[kk] = vv / len(state_dicts)
-        model.load_state_dict(state_dict)
+        parts = [cls._filter_state(cls._read_ckpt(os.path.join(model_folder_path, n)))
+                 for n in cls._best_checkpoints(model_folder_path)]
+        if not parts:
+            raise FileNotFoundError(f"no vocos_* checkpoint in {model_folder_path}")
+        mean_state = {}
+        for key, first in parts[0].items():
+            total = first.clone()
+            for other in parts[1:]:
+                total += other[key]
+            mean_state[key] = total / len(parts)
+        model.load_state_dict(mean_state)
         model.eval()
         return model
 
@@ -367,7 +379,7 @@ class WavTokenizer(nn.Module):
     # -- packed image: what sits in HBM after loading, ready to upload again ------------------------------
     def save_packed(self, path: str) -> None:
         """Write the model as it sits in HBM (folded conv weights in [Cout][tap][Cin], LSTM lane packings, the packed
-        ISTFT head and inverse-DFT basis, the S32 / f16x2 split copies and their scales) behind a header with a layout
+        ISTFT head and inverse-DFT basis, the S32 split copies and their scales) behind a header with a layout
         version and an architecture hash.  from_packed uploads it without folding, packing or splitting anything again.
         The model must be on the GPU (the image is read back from there)."""
         self._ensure_engine()
@@ -384,11 +396,21 @@ class WavTokenizer(nn.Module):
         check(lib.wt_packed_info(image.ctypes.data_as(ctypes.c_void_p), image.nbytes, ctypes.byref(wa), ctypes.byref(ver),
                                  ctypes.byref(ah)), "wt_packed_info")
         a = model._arch
-        mine = (len(a.ratios), tuple(a.ratios), a.vq_bins, a.dim, a.intermediate_dim, a.num_layers, a.n_fft, a.hop_length)
-        theirs = (wa.n_ratios, tuple(wa.ratios[i] for i in range(wa.n_ratios)), wa.vq_bins, wa.dim, wa.intermediate_dim,
-                  wa.num_layers, wa.n_fft, wa.hop_length)
-        if mine != theirs:
-            raise ValueError(f"packed file was written for another architecture: {theirs} (config says {mine})")
+        # every field of wt_arch: the library sizes its launches from the image's architecture while this class sizes the
+        # tensors it hands over from the config's (a 'same' image under a 'center' config would be written B*hop floats
+        # past the end of the waveform tensor), so any difference is an error
+        mine = {"ratios": tuple(a.ratios), "vq_bins": a.vq_bins, "num_quantizers": a.num_quantizers,
+                "input_channels": a.input_channels, "dim": a.dim, "intermediate_dim": a.intermediate_dim,
+                "num_layers": a.num_layers, "adanorm_num_embeddings": a.adanorm_num_embeddings, "n_fft": a.n_fft,
+                "hop_length": a.hop_length, "padding": a.padding}
+        theirs = {"ratios": tuple(wa.ratios[i] for i in range(wa.n_ratios)), "vq_bins": wa.vq_bins,
+                  "num_quantizers": wa.num_quantizers, "input_channels": wa.input_channels, "dim": wa.dim,
+                  "intermediate_dim": wa.intermediate_dim, "num_layers": wa.num_layers,
+                  "adanorm_num_embeddings": wa.adanorm_num_embeddings, "n_fft": wa.n_fft, "hop_length": wa.hop_length,
+                  "padding": "same" if wa.padding_same else "center"}
+        diff = {k: (theirs[k], mine[k]) for k in mine if mine[k] != theirs[k]}
+        if diff:
+            raise ValueError(f"packed file was written for another architecture (field: (file, config)): {diff}")
         dev = torch.device(device)
         model.eval()
         model = model.to(dev)
@@ -444,8 +466,9 @@ class WavTokenizer(nn.Module):
     def set_strict_status(self, on: bool):
         """Device-side failures of a call (an activation beyond the f16 range of the split-f16 form; a persistent-LSTM step
         barrier that timed out) always overwrite that call's outputs (codes = -1, NaN) and surface as an error on the
-        NEXT call on the same plan, which this class answers by falling back (fp32 GEMMs / launch-per-step LSTM) and
-        running that next call.  strict=True additionally synchronises after every call, checks, falls back and REPEATS
+        NEXT call on this model, whatever its shape (the library keeps one host-mapped status word per model beside the
+        per-plan ones), which this class answers by falling back for good (fp32 GEMMs / launch-per-step LSTM for every
+        plan of the model) and running that next call.  strict=True additionally synchronises after every call, checks, falls back and REPEATS
         the failed call itself, so no poisoned result is ever handed out (costs the host/GPU overlap between calls)."""
         self._strict = bool(on)
 
@@ -461,6 +484,15 @@ class WavTokenizer(nn.Module):
                 bad.append((key, bits.value))
                 if bits.value & _capi.WT_STATUS_BIT_RANGE:
                     self._plan_flags |= _capi.WT_PLAN_FLAG_FP32_GEMM
+        mbits = ctypes.c_int32()
+        if self._engine.model:
+            # the model's own word: failures of plans that the LRU has destroyed since are still recorded there
+            check(lib.wt_model_status(self._engine.model, ctypes.byref(mbits), 1), "wt_model_status")
+            if mbits.value & _capi.WT_STATUS_BIT_RANGE:
+                self._plan_flags |= _capi.WT_PLAN_FLAG_FP32_GEMM
+            if mbits.value and not bad:
+                bad.append(("model", mbits.value))
+        self._poll_bad_codes()
         if bad:
             raise WavTokError("device-side failure in earlier calls (plan key, status bits): %s; their outputs were "
                               "overwritten with -1 / NaN; later calls fall back (fp32 GEMMs / step LSTM)" % bad)
@@ -472,6 +504,17 @@ class WavTokenizer(nn.Module):
             raise ValueError("mode must be 'f16x3' or 'f32'")
         self._plan_flags = (self._plan_flags | _capi.WT_PLAN_FLAG_FP32_GEMM) if mode == "f32" else \
             (self._plan_flags & ~_capi.WT_PLAN_FLAG_FP32_GEMM)
+
+    def set_check_codes(self, mode: str):
+        """How codes_to_features reports an index outside the codebook: "deferred" (default; IndexError on the next call
+        on this model or in check_status(), no stream synchronisation), "sync" (synchronise and raise at once) or "off"."""
+        if mode not in ("deferred", "sync", "off"):
+            raise ValueError("mode must be 'deferred', 'sync' or 'off'")
+        self._check_codes = mode
+
+    def _poll_bad_codes(self):
+        if self._check_codes != "off" and self._engine.model and lib.wt_model_take_bad_codes(self._engine.model):
+            raise IndexError("index out of range in self")
 
     def set_graph_max_clips(self, n: int):
         """Largest batch whose encode / decode plans are recorded and replayed as a hipGraph (default 16; 0 = never)."""
@@ -539,6 +582,7 @@ class WavTokenizer(nn.Module):
         if self._dirty or self._engine.device_index != idx:
             self._engine.load(self._arch, self.state_dict(), idx)
             self._dirty = False
+        self._poll_bad_codes()          # an earlier codes_to_features met a bad index (deferred mode: found without a sync)
         return torch.device("cuda", idx)
 
     @staticmethod
@@ -584,8 +628,12 @@ class WavTokenizer(nn.Module):
                 raise ValueError("bandwidth_id must hold one index (the reference broadcasts a (1, dim) embedding row)")
             if bandwidth_id.device.type == "cpu":
                 return int(bandwidth_id.reshape(-1)[0])
-            # a tensor on the GPU (infer.py:52 builds it there once and passes it to every call): reading it is a
-            # device synchronisation, so the value is remembered per tensor object and version
+            # a tensor on the GPU: reading it is a device synchronisation, so the value is remembered per tensor object and
+            # version for callers that build it once and pass it to every call.  Tensors made under torch.inference_mode()
+            # carry no version counter (reading _version raises): those are read every time, like the reference's
+            # infer.py:60-62 does with the new tensor it builds per file
+            if bandwidth_id.is_inference():
+                return int(bandwidth_id.reshape(-1)[0])
             c = self._bw_cache
             if c is not None and c[0]() is bandwidth_id and c[1] == bandwidth_id._version:
                 return c[2]
@@ -699,10 +747,9 @@ class WavTokenizer(nn.Module):
         feats = torch.empty((B, 512, L), dtype=torch.float32, device=dev)
         check(lib.wt_codes_to_features(self._engine.model, _ptr(codes), K, B, L, _ptr(feats), _stream_ptr(dev)),
               "wt_codes_to_features")
-        if self._check_codes:
+        if self._check_codes == "sync":
             # F.embedding raises on an index outside the codebook (pretrained.py:236); the kernel flags it instead (and
             # writes NaN), which is read here after the (few microseconds of) work has completed
             torch.cuda.current_stream(dev).synchronize()
-            if lib.wt_model_take_bad_codes(self._engine.model):
-                raise IndexError("index out of range in self")
+            self._poll_bad_codes()
         return feats

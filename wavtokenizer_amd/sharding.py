@@ -108,3 +108,82 @@ def roundtrip_sharded(model, wav_all: torch.Tensor, bandwidth_id: torch.Tensor, 
     feats, codes = model.encode_infer(wav_all[lo:hi].contiguous(), bandwidth_id=bandwidth_id)
     out = model.decode(feats, bandwidth_id=bandwidth_id)
     return gather_codes(codes, dist, world, counts), gather_waveforms(out, dist, world, rank, dst, counts)
+
+
+class StepRunner:
+    """encode_infer + decode steps of one (model, batch) with the end-of-step exchange of the sharded mode (bench.py
+    --gpus N drives this; the world-2 tests drive it with a recording stub in place of the model).
+
+    Ordering invariant: the exchange of step i (codes to every rank, 8*L bytes per clip; waveforms to
+    rank `dst`) is ISSUED right after step i+1's encode_infer has been enqueued and COLLECTED before step i+1 returns.
+    On RCCL the collective's stream waits for what was enqueued before it, so its kernels start when that encode has
+    finished on the GPU, run beside step i+1's decode, and the next encode is ordered behind them by the collecting
+    stream wait: RCCL never runs beside lstm_persist_kernel, which needs every CU for its resident workgroups
+    (wavtokenizer_amd/csrc/lstm_persist.hip).  `log`, when given, receives (event, step) tuples in host order:
+    "encode", "issue", "decode", "collect" - the tests assert the invariant on it."""
+
+    def __init__(self, model, wav, bw, dist, world, rank, gather=True, backend="nccl", dst=0, log=None):
+        self.model, self.wav, self.bw = model, wav, bw
+        self.dist, self.world, self.rank, self.backend, self.dst = dist, world, rank, backend, dst
+        self.gather = bool(gather) and world > 1
+        self.prev = None            # (step index, codes, waveform) of the previous step, not yet exchanged
+        self.i = 0
+        self.log = log
+        self.wait_s = 0.0           # host time spent collecting exchanges (PendingGather.result)
+        self.exchanges = 0
+
+    def _note(self, what, step):
+        if self.log is not None:
+            self.log.append((what, step))
+
+    def _issue(self):
+        step, codes, out = self.prev
+        self.prev = None
+        if self.backend == "gloo":                               # rehearsal only: through host memory
+            codes, out = codes.cpu(), out.cpu()
+        self._note("issue", step)
+        return step, gather_async(codes, out, self.dist, self.world, self.rank, dst=self.dst)
+
+    def _collect(self, pend):
+        import time
+        step, p = pend
+        t0 = time.perf_counter()
+        res = p.result()
+        self.wait_s += time.perf_counter() - t0
+        self.exchanges += 1
+        self._note("collect", step)
+        return res
+
+    def step(self):
+        i = self.i
+        self.i += 1
+        feats, codes = self.model.encode_infer(self.wav, bandwidth_id=self.bw)
+        self._note("encode", i)
+        pend = self._issue() if (self.gather and self.prev is not None) else None
+        out = self.model.decode(feats, bandwidth_id=self.bw)
+        self._note("decode", i)
+        res = self._collect(pend) if pend is not None else None
+        if self.gather:
+            self.prev = (i, codes, out)
+        return codes, out, res
+
+    def drain(self):
+        """The exchange of the last step: issued and collected here (inside the timed region of bench.py)."""
+        if self.gather and self.prev is not None:
+            return self._collect(self._issue())
+        return None
+
+
+def check_exchange_order(log, n_steps):
+    """Asserts DESIGN section 6's invariant on a StepRunner log of n_steps steps followed by drain()."""
+    pos = {ev: k for k, ev in enumerate(log)}
+    assert len(pos) == len(log), "an event was logged twice"
+    for i in range(n_steps):
+        assert pos[("encode", i)] < pos[("decode", i)]
+        if i + 1 < n_steps:
+            # issued after the NEXT encode is enqueued, before the next decode; collected before the step after that begins
+            assert pos[("encode", i + 1)] < pos[("issue", i)] < pos[("decode", i + 1)] < pos[("collect", i)]
+            if i + 2 < n_steps:
+                assert pos[("collect", i)] < pos[("encode", i + 2)]
+        else:
+            assert pos[("decode", i)] < pos[("issue", i)] < pos[("collect", i)]      # the drain

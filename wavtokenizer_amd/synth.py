@@ -213,6 +213,53 @@ def make_state_dict(arch: ArchConfig, seed: int = 0, with_seanet_decoder: bool =
     return sd
 
 
+def make_trained_like_state_dict(arch: ArchConfig, seed: int = 7, with_seanet_decoder: bool = False) -> Dict[str, np.ndarray]:
+    """A second synthetic recipe whose STATISTICS resemble a trained checkpoint rather than an init (no trained weights
+    exist offline): starting from make_state_dict, every tensor class gets the spread that training produces and that the
+    split-f16 (S32) arithmetic has to survive:
+      * weight_g of the weight-normed convs: log-normal per channel (sigma 0.7: some channels 4x up, some 4x down)
+      * conv / linear weight matrices: heavy-tailed (element-wise log-normal factor, sigma 0.5, plus 0.1 % outliers x8),
+        each output row renormalised to its former L2 norm so the activations stay O(1)
+      * ConvNeXt layer scale gamma: log-normal around 0.3 with a tail up to 10
+      * LayerNorm / AdaLayerNorm / GroupNorm scales: log-normal, sigma 0.5 (0.25 .. 4); shifts and biases 3x larger
+      * codebook rows: per-row log-normal radius (sigma 0.3)
+    tests/golden/make_golden_trained_like.py pins the reference's outputs on it; tests/test_gpu_parity.py compares."""
+    sd = make_state_dict(arch, seed=seed, with_seanet_decoder=with_seanet_decoder)
+
+    def lognorm(key, n, sigma):
+        return np.exp(sigma * _approx_normal(key + "#ln", n, seed))
+
+    for k in list(sd.keys()):
+        v = sd[k]
+        if k.endswith(".weight_g"):
+            sd[k] = (v.astype(np.float64) * lognorm(k, v.size, 0.7).reshape(v.shape)).astype(np.float32)
+        elif k.endswith(".gamma"):
+            g = 0.3 * lognorm(k, v.size, 1.2)
+            sd[k] = np.minimum(g, 10.0).astype(np.float32)
+        elif (k.endswith(".weight_v") or k.endswith(".weight")) and v.ndim >= 2 and v.shape[0] > 4 and "norm" not in k and "lstm" not in k:
+            w = v.astype(np.float64)
+            rows = w.reshape(w.shape[0], -1)
+            n0 = np.sqrt((rows ** 2).sum(axis=1, keepdims=True))
+            f = lognorm(k, rows.size, 0.5).reshape(rows.shape)
+            out_mask = _uniform(k + "#out", rows.size, seed).reshape(rows.shape) < 1e-3
+            rows2 = rows * f * np.where(out_mask, 8.0, 1.0)
+            n1 = np.sqrt((rows2 ** 2).sum(axis=1, keepdims=True))
+            sd[k] = (rows2 * (n0 / np.maximum(n1, 1e-30))).reshape(w.shape).astype(np.float32)
+        elif ("norm" in k or k.startswith("backbone.pos_net.5")) and k.endswith(".weight"):
+            # GroupNorm / LayerNorm weights (n,) and AdaLayerNorm scale/shift tables (A, D)
+            if ".shift." in k:
+                sd[k] = (3.0 * v).astype(np.float32)
+            else:
+                sd[k] = (np.sign(v) * np.abs(v.astype(np.float64)) * lognorm(k, v.size, 0.5).reshape(v.shape)).astype(np.float32)
+        elif k.endswith(".bias") and "lstm" not in k and "head.out" not in k:
+            sd[k] = (3.0 * v).astype(np.float32)
+        elif k.endswith("_codebook.embed"):
+            r = lognorm(k, v.shape[0], 0.3).reshape(-1, 1)
+            sd[k] = (v.astype(np.float64) * r).astype(np.float32)
+    sd[VQ + "embed_avg"] = sd[VQ + "embed"].copy()
+    return sd
+
+
 def weights_manifest(sd: Dict[str, np.ndarray]) -> Dict[str, Dict]:
     return {k: {"shape": list(v.shape), "sha256": hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest()}
             for k, v in sorted(sd.items())}
