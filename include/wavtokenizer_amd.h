@@ -127,6 +127,8 @@ size_t wt_model_export_bytes(const wt_model* m);
 int  wt_model_export(const wt_model* m, void* buf, size_t n);
 int  wt_packed_info(const void* buf, size_t n, wt_arch* arch, int32_t* version, uint64_t* arch_hash);
 int  wt_packed_verify(const void* buf, size_t n);
+/* exact length of the image that starts at buf (wt_model_export_bytes is an upper bound); 0 when the header is not valid */
+size_t wt_packed_bytes(const void* buf, size_t n);
 int  wt_model_create_packed(const void* buf, size_t n, int32_t device, wt_model** out);
 int  wt_model_hop(const wt_model* m);                 /* prod(ratios) */
 int64_t wt_model_weight_bytes(const wt_model* m);     /* packed fp32 bytes resident in HBM */

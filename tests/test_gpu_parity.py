@@ -905,7 +905,8 @@ def test_persistent_lstm_lost_coresidency(gpu_model):
     import ctypes
     import os
     from wavtokenizer_amd import _capi, synth
-    name, m, sd = gpu_model
+    name, _shared, sd = gpu_model
+    m = _fresh_model(name, sd)              # the fallback is sticky for a model: not on the module's shared one
     wav = torch.from_numpy(synth.make_clips(20, 7200, seed=520)).cuda()
     m.set_lstm_mode("step")
     try:
@@ -928,8 +929,11 @@ def test_persistent_lstm_lost_coresidency(gpu_model):
     assert bits.value & _capi.WT_STATUS_BIT_LSTM
     f2, c2 = m.encode_infer(wav, bandwidth_id=BW)          # WT_ERR_LSTM_SYNC inside -> step kernel -> runs
     assert torch.equal(c2, c_ref) and torch.equal(f2, f_ref)
-    # strict mode repeats the failing call itself
-    m._engine.drop(lambda k: k[0] == _capi.WT_PLAN_ENCODE)
+    with pytest.raises(_capi.WavTokError, match="fallback"):
+        m.check_status()                                   # the answered failure is still reported once
+    m.check_status()
+    # strict mode repeats the failing call itself (a fresh model: the first one runs the step LSTM for good now)
+    m = _fresh_model(name, sd)
     m.set_strict_status(True)
     os.environ["WT_LSTM_PERSIST_FAULT"] = "1"
     try:
@@ -1196,8 +1200,11 @@ def test_device_failure_reaches_the_next_call_on_another_plan(gpu_model):
         del os.environ["WT_LSTM_PERSIST_FAULT"]
     assert torch.equal(c2, refs[0][1]) and torch.equal(f2, refs[0][0]), "the next call on another plan must fall back and be correct"
     assert torch.equal(c3, refs[1][1]) and torch.equal(f3, refs[1][0])
-    m.check_status()                                    # nothing left pending: every failure was consumed and answered
     assert dt2 < 5.0
+    assert len(m.fallback_events) == 1                  # one failure, answered once, for the whole model
+    with pytest.raises(_capi.WavTokError, match="fallback"):
+        m.check_status()                                # reported once (the first call's poisoned outputs were handed out) ...
+    m.check_status()                                    # ... and nothing is left pending: plan A's stale word does not come back
 
 
 def test_bandwidth_id_tensor_created_under_inference_mode(gpu_model):

@@ -100,7 +100,6 @@ def main():
         os.environ["WT_GEMM16S_DBG"] = "5"
         linear("pwconv1 s32 128x192x3 no DMA, no epilogue", 7680, 2304, 768, 2, 2)
         os.environ.pop("WT_GEMM16S_DBG")
-        linear("pwconv1 s32 128x96x2", 7680, 2304, 768, 2, 1)
         json.dump(calls, open(sys.argv[1], "w"))
         return
     if len(sys.argv) > 2 and sys.argv[2] == "dbg":
@@ -114,21 +113,9 @@ def main():
                 os.environ.pop("WT_GEMM16S_DBG")
         json.dump(calls, open(sys.argv[1], "w"))
         return
-    if len(sys.argv) > 2 and sys.argv[2] == "dbg2":        # the 8-wave tile against the 4-wave / 512-register one, rung by rung
-        WARM, REPS = 30, 40
-        for tile in (2, 10):
-            linear(f"pwconv1 bias->fp32 tile {tile} shipped", 7680, 2304, 768, 2, tile)
-            linear(f"pwconv1 bias->S32 tile {tile} shipped", 7680, 2304, 768, 3, tile)
-            linear(f"pwconv1 gelu->S32 tile {tile} shipped", 7680, 2304, 768, 4, tile)
-            for dbg, dn in ((1024, "full (stamped)"), (4, "no epilogue"), (5, "no epilogue, no DMA"), (45, "MFMA + LDS fragment reads")):
-                os.environ["WT_GEMM16S_DBG"] = str(dbg)
-                linear(f"pwconv1 bias->fp32 tile {tile}: {dn}", 7680, 2304, 768, 2, tile)
-                os.environ.pop("WT_GEMM16S_DBG")
-        json.dump(calls, open(sys.argv[1], "w"))
-        return
     if len(sys.argv) > 2 and sys.argv[2] == "tune":
         for name, M, N, K in [("pwconv1", 7680, 2304, 768), ("pwconv2", 7680, 768, 2304)]:
-            for tile, tn in ((2, "128x192x3"), (1, "128x96x2"), (6, "128x192x2"), (7, "256x128x3"), (3, "128x128x3")):
+            for tile, tn in ((2, "128x192x3"), (3, "128x128x3")):
                 linear(f"{name} s32 {tn}", M, N, K, 2, tile)
             os.environ["WT_GEMM16S_NONPERSISTENT"] = "1"
             linear(f"{name} s32 128x192x3 non-persistent", M, N, K, 2, 2)
@@ -140,12 +127,11 @@ def main():
               ("hop320 pw1", 14400, 2304, 768), ("ragged", 7000, 800, 96)]
     for name, M, N, K in shapes:
         linear(f"{name} fp32", M, N, K, 0)
-        linear(f"{name} f16x3 in-loop", M, N, K, 1)
-        for tile, tn in ((1, "128x96x2"), (2, "128x192"), (3, "128x128")):
+        for tile, tn in ((2, "128x192"), (3, "128x128")):
             linear(f"{name} s32 {tn}", M, N, K, 2, tile)
         if N % 32 == 0:
             linear(f"{name} s32 auto ->S32", M, N, K, 3)
-    for tile, tn in ((1, "128x96x2"), (2, "128x192"), (3, "128x128")):
+    for tile, tn in ((2, "128x192"), (3, "128x128")):
         conv(f"res k3 768 {tn}", 64, 120, 768, 768, 3, 1, 1, tile)
         conv(f"embed k7 512 {tn}", 64, 120, 512, 768, 7, 1, 1, tile)
     conv("down k10 s5 reflect", 8, 3600, 128, 256, 10, 5, 0)

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("WAVTOK_HIP_LIB") or os.path.join(_HERE, "libwavtok_hi
 
 # every symbol include/wavtokenizer_amd.h declares
 EXPORTS = [
-    "wt_last_error", "wt_version", "wt_model_create", "wt_model_destroy", "wt_model_export_bytes", "wt_model_export", "wt_packed_info", "wt_packed_verify",
+    "wt_last_error", "wt_version", "wt_model_create", "wt_model_destroy", "wt_model_export_bytes", "wt_model_export", "wt_packed_info", "wt_packed_verify", "wt_packed_bytes",
     "wt_model_create_packed", "wt_model_hop", "wt_model_weight_bytes",
     "wt_plan_create", "wt_plan_destroy", "wt_plan_workspace_bytes", "wt_plan_frames", "wt_plan_num_launches", "wt_plan_graph_replays",
     "wt_plan_find_buffer", "wt_plan_buffer_info", "wt_plan_buffer_name", "wt_plan_status", "wt_plan_num_steps", "wt_plan_step_name",
@@ -60,6 +60,20 @@ def _load() -> ctypes.CDLL:
             f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
             "or make -C wavtokenizer_amd/csrc). There is no CPU fallback for the product path.")
     lib = ctypes.CDLL(LIB_PATH)
+    if os.environ.get("WAVTOK_HIP_LIB"):
+        # A/B timing against an older build of the library (tools/build_prev.sh): entry points it does not have yet are
+        # replaced by a stub that fails when called, so that the timing tools can still bind the ones they use
+        class _Missing:
+            def __init__(self, name):
+                self.name, self.argtypes, self.restype = name, None, None
+
+            def __call__(self, *a):
+                raise WavTokError(f"{LIB_PATH} has no {self.name}")
+        for sym in EXPORTS:
+            try:
+                getattr(lib, sym)
+            except AttributeError:
+                setattr(lib, sym, _Missing(sym))
     lib.wt_last_error.restype = c_char_p
     lib.wt_version.restype = c_char_p
     lib.wt_model_create.argtypes = [POINTER(WtArch), POINTER(WtTensor), c_int32, c_int32, POINTER(c_void_p)]
@@ -70,6 +84,8 @@ def _load() -> ctypes.CDLL:
     lib.wt_model_export.argtypes = [c_void_p, c_void_p, c_size_t]
     lib.wt_packed_info.argtypes = [c_void_p, c_size_t, POINTER(WtArch), POINTER(c_int32), POINTER(ctypes.c_uint64)]
     lib.wt_packed_verify.argtypes = [c_void_p, c_size_t]
+    lib.wt_packed_bytes.argtypes = [c_void_p, c_size_t]
+    lib.wt_packed_bytes.restype = c_size_t
     lib.wt_model_create_packed.argtypes = [c_void_p, c_size_t, c_int32, POINTER(c_void_p)]
     lib.wt_model_hop.argtypes = [c_void_p]
     lib.wt_model_weight_bytes.argtypes = [c_void_p]

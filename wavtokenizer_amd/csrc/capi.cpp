@@ -71,6 +71,7 @@ int wt_model_export(const wt_model* m, void* buf, size_t n) {
 int wt_packed_info(const void* buf, size_t n, wt_arch* arch, int32_t* version, uint64_t* arch_hash) {
     return packed_info(buf, n, arch, version, arch_hash);
 }
+size_t wt_packed_bytes(const void* buf, size_t n) { return buf ? packed_bytes(buf, n) : 0; }
 int wt_packed_verify(const void* buf, size_t n) {
     try { return packed_verify(buf, n); }
     catch (const std::exception& e) { set_error(std::string("wt_packed_verify: ") + e.what()); return WT_ERR_INVALID; }
@@ -207,22 +208,25 @@ int wt_plan_buffer_name(const wt_plan* p, int32_t index, const char** name) {
     return WT_OK;
 }
 
-// Consumes the failure bits that earlier calls left behind (the plan's lock is held): those of this plan's own word
-// and those of the MODEL's word, into which every plan's guard step reports as well, so that a caller who never uses a plan
-// twice (one new length per file) still meets the error on its next call.  After a lost-co-residency report every plan
+// Consumes the failure bits that earlier calls left behind (the plan's lock is held).  Every plan's guard step reports
+// into two host-mapped words: the plan's own (attribution: wt_plan_status) and the MODEL's, which is the one that makes
+// the next call fail: a caller who never uses a plan twice (one new length per file) still meets the error on its next
+// call, and a failure that another plan's call has already consumed and answered is not reported a second time when
+// this plan runs again (its own word is then stale and is just cleared).  After a lost-co-residency report every plan
 // of the model runs the LSTM one launch per step from now on (wt_model::persist_ok), and a recorded graph that holds a
-// persistent launch is dropped.
-static unsigned consume_status(const wt_plan* p) {
+// persistent launch is dropped.  Returns the model's bits; *own receives this plan's.
+static unsigned consume_status(const wt_plan* p, unsigned* own = nullptr) {
     const wt_model* M = p->model;
-    unsigned bits = p->status_host ? __atomic_exchange_n(p->status_host, 0u, __ATOMIC_ACQUIRE) : 0u;
-    if (M->status_host) bits |= __atomic_exchange_n(M->status_host, 0u, __ATOMIC_ACQUIRE);
-    if (bits & WT_STATUS_LSTM) M->persist_ok.store(false);
+    const unsigned pb = p->status_host ? __atomic_exchange_n(p->status_host, 0u, __ATOMIC_ACQUIRE) : 0u;
+    const unsigned mb = M->status_host ? __atomic_exchange_n(M->status_host, 0u, __ATOMIC_ACQUIRE) : 0u;
+    if ((mb | pb) & WT_STATUS_LSTM) M->persist_ok.store(false);
     if (p->graph_exec && p->graph_persist && !M->persist_ok.load()) {
         (void)hipGraphExecDestroy(p->graph_exec);
         p->graph_exec = nullptr; p->graph_persist = false;
         p->last_key = wt_plan::GraphKey{};
     }
-    return bits;
+    if (own) *own = pb;
+    return mb;
 }
 
 static int run_plan_locked(const wt_plan* p, const RunCtx& c);
@@ -318,7 +322,8 @@ int wt_plan_status(const wt_plan* p, int32_t* bits, int32_t clear) {
     unsigned b;
     if (clear) {
         DeviceGuard dg(p->model->device);
-        b = consume_status(p);
+        unsigned own = 0;
+        b = consume_status(p, &own) | own;      // this plan's failures and whatever the model's word still held
     } else {
         b = p->status_host ? __atomic_load_n(p->status_host, __ATOMIC_ACQUIRE) : 0u;
     }

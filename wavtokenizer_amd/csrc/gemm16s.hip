@@ -87,6 +87,38 @@ __device__ __forceinline__ f32x4 gelu_erf_s4(f32x4 v) {
     return (f32x4){lo.x, lo.y, hi.x, hi.y};
 }
 
+// GELU through erfc on ONE branch: with a = x / sqrt(2), gelu(x) = x * (1 - h) for x >= 0 and x * h for x < 0, where
+// h = erfc(|a|) / 2 = 2^p(|a|): p is a degree-9 minimax fit of log2(erfc(t)) - 1 on [0, 4.3] (weighted for the absolute
+// error of erfc: 2e-9 in exact arithmetic; |a| is clamped to 4.3, beyond which h < 6e-10).  No second polynomial, no select
+// between two formulas, and no cancellation on the negative side (h is formed with relative accuracy, where the
+// reference's own fp32 1 + erf(a) carries the rounding of erf near -1): simulated in fp32 against float64 on 2.4 M
+// inputs the maximum absolute error is 3.9e-7 (torch's fp32 gelu: 1.2e-6), rms relative 1.0e-7 (2.3e-6).
+__device__ __forceinline__ f32x2 gelu_erfc_s2(f32x2 x) {
+    const f32x2 a = x * 0.70710678118654752440f;
+    f32x2 t = __builtin_elementwise_abs(a);
+    t.x = fminf(t.x, 4.3f); t.y = fminf(t.y, 4.3f);
+    f32x2 p = fma2((f32x2)(1.146792511e-05f), t, (f32x2)(-1.515573094e-04f));
+    p = fma2(p, t, (f32x2)(8.423082181e-04f));
+    p = fma2(p, t, (f32x2)(-2.261521295e-03f));
+    p = fma2(p, t, (f32x2)(6.768874300e-05f));
+    p = fma2(p, t, (f32x2)(2.773740143e-02f));
+    p = fma2(p, t, (f32x2)(-1.483134478e-01f));
+    p = fma2(p, t, (f32x2)(-9.184416533e-01f));
+    p = fma2(p, t, (f32x2)(-1.627907395e+00f));
+    p = fma2(p, t, (f32x2)(-1.0f));
+    f32x2 h;
+    h.x = __builtin_amdgcn_exp2f(p.x);
+    h.y = __builtin_amdgcn_exp2f(p.y);
+    f32x2 s;
+    s.x = a.x >= 0.f ? 1.f - h.x : h.x;
+    s.y = a.y >= 0.f ? 1.f - h.y : h.y;
+    return x * s;
+}
+__device__ __forceinline__ f32x4 gelu_erfc_s4(f32x4 v) {
+    const f32x2 lo = gelu_erfc_s2((f32x2){v.x, v.y}), hi = gelu_erfc_s2((f32x2){v.z, v.w});
+    return (f32x4){lo.x, lo.y, hi.x, hi.y};
+}
+
 // fp32 value -> S32 slots of element n (n & 31 = slot) in the group that starts at `grp` (a _Float16*)
 __device__ __forceinline__ void store_s32(_Float16* grp, int slot, float v) {
     const _Float16 h = (_Float16)v;
@@ -103,6 +135,20 @@ __device__ __forceinline__ void store_s32_x4(float* row, int n, const f32x4 v, f
     _Float16* g = reinterpret_cast<_Float16*>(row) + ((n >> 5) * 64 + (n & 31));
     *reinterpret_cast<f16x4*>(g) = hi;
     *reinterpret_cast<f16x4*>(g + 32) = lo;
+}
+
+// 16 bytes of an output tile.  SC1: write-through store that does not keep the line in this XCD's L2 (MI355X_MICROARCH.md,
+// "stores of each flavour"): the C tile is never read again by this kernel, and 71 MB of it per launch otherwise push the
+// A / W panels, which ARE re-read, out of the 4 MiB L2 (pwconv1: -1.4 us of 93, tools/micro/gemm_lab.hip)
+template <bool SC1>
+__device__ __forceinline__ void store_c16(float* dst, const f32x4 v) {
+    if constexpr (SC1) {
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        const u32x4_t qv = __builtin_bit_cast(u32x4_t, v);
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(qv) : "memory");
+    } else {
+        *reinterpret_cast<f32x4*>(dst) = v;
+    }
 }
 
 template <int N>
@@ -133,7 +179,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
     static_assert((NSTAGE - 2) * NPT < 64, "vmcnt field");
     extern __shared__ __attribute__((aligned(1024))) char smem_s[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the wave index as a SCALAR: with threadIdx.x >> 6 in a vector register every LDS-DMA destination (M0) went through
+    // v_add + v_readfirstlane + s_mov per piece, and every per-wave offset cost vector instructions
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = (dbg & 65536) ? (tid >> 6) : __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int ntiles = tiles_m * tiles_n;
@@ -243,6 +292,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
     };
     auto loader_set_tile = [&](int vb, int par) {       // the table of `vb` (parity par) must be visible
         l_vb = vb; l_par = par; tapL = 0; ciL = 0; kL = 0;
+        if (dbg & 131072) l_mask = OOB;          // timing experiment: every DMA is issued but fetches nothing (zero fill)
         if (vb >= ntiles) { l_mask = OOB; return; }
         int bm, bn;
         tile_coords(vb, bm, bn);
@@ -266,24 +316,46 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
         }
         set_tap(0);
     };
+    // one DMA piece of the K tile the loader stands at (idx < NPA: activation rows, else weight rows); load_advance() moves on
+    auto load_piece = [&](int stage, auto idx_c) {
+        constexpr int idx = decltype(idx_c)::value;
+        char* sbase = smem_s + stage * STG + wave * 1024;
+        if constexpr (idx < NPA) {
+            // the K advance rides in the instruction's scalar offset (it is not part of the range check, which the
+            // out-of-range marker in the vector offset still fails): no vector add per piece
+            if (p.A2 && kL >= p.K1)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr_t)(sbase + NW * idx * 1024), 16,
+                                                         (int)(a2_voff[idx] | l_mask), (kL - p.K1) * 4, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(sbase + NW * idx * 1024), 16,
+                                                         (int)(a_voff[idx] | l_mask), ciL * 4, 0, 0);
+        } else {
+            constexpr int j = idx - NPA;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(sbase + (BM / 8 + NW * j) * 1024), 16,
+                                                     (int)(w_voff[j] | l_mask), kL * 4, 0, 0);
+        }
+    };
+    auto load_advance = [&]() {
+        kL += SBK; ciL += SBK;
+        if (kL >= p.K) {
+            if (l_mask == 0) loader_set_tile(l_vb + G, l_par ^ 1);     // on into the next output tile
+        } else if (p.taps > 1 && ciL >= p.Cin) {
+            ciL = 0; ++tapL; set_tap(tapL);
+        }
+    };
     auto load_tile = [&](int stage) {
-        const unsigned kadvA = (unsigned)ciL * 4u, kadvW = (unsigned)kL * 4u;
         char* sbase = smem_s + stage * STG + wave * 1024;
         if (p.A2 && kL >= p.K1) {                                    // wave-uniform: this K tile comes from the second source
-            const unsigned kadv2 = (unsigned)(kL - p.K1) * 4u;
 #pragma unroll
             for (int i = 0; i < NPA; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr_t)(sbase + NW * i * 1024), 16,
-                                                         (int)((a2_voff[i] | l_mask) + kadv2), 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr_t)(sbase + NW * i * 1024), 16, (int)(a2_voff[i] | l_mask), (kL - p.K1) * 4, 0, 0);
         } else
 #pragma unroll
         for (int i = 0; i < NPA; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(sbase + NW * i * 1024), 16,
-                                                     (int)((a_voff[i] | l_mask) + kadvA), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(sbase + NW * i * 1024), 16, (int)(a_voff[i] | l_mask), ciL * 4, 0, 0);
 #pragma unroll
         for (int j = 0; j < NPB; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(sbase + (BM / 8 + NW * j) * 1024), 16,
-                                                     (int)((w_voff[j] | l_mask) + kadvW), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(sbase + (BM / 8 + NW * j) * 1024), 16, (int)(w_voff[j] | l_mask), kL * 4, 0, 0);
         kL += SBK; ciL += SBK;
         if (kL >= p.K) {
             if (l_mask == 0) loader_set_tile(l_vb + G, l_par ^ 1);     // on into the next output tile
@@ -362,12 +434,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
             F.l[j] = *reinterpret_cast<const f16x8*>(sB + j * 16 * 128 + fo16l);
         }
     };
-    auto mfma16_block = [&](const FragA& A, const FragB& Bf, auto half_c) {
+    auto mfma16_block = [&](const FragA& A, const FragB& Bf, auto half_c, auto&& between) {
         constexpr int half = decltype(half_c)::value;          // a constant: the accumulators must stay in registers
 #pragma unroll
         for (int jj = 0; jj < TNH; ++jj)
 #pragma unroll
             for (int i = 0; i < TM16; ++i) {
+                between(jj * TM16 + i);
                 constexpr int jbase = half * TNH;
                 const int j = jbase + jj;
                 f32x4& m = am[MF ? i : 0][MF ? j : 0];
@@ -448,21 +521,38 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
         for (int kt = 0; kt < nk; ++kt) {
             // (tried: the younger half of the waves issuing its DMA pieces after the first-half MFMAs instead of before them,
             // so that one wave's DMA issue runs beside its SIMD partner's MFMAs: 5.79 vs 5.80 ms per step A/B on one box: nothing)
-            if (!(dbg & 1)) load_tile(ws);
+            constexpr bool SPREAD = MF && !(dbg & 2048) && NPT <= TNH * TM16;     // one DMA piece in front of each MFMA group (below)
+            if (!(dbg & 1) && !SPREAD) load_tile(ws);
             if (MF) {
                 if (!(dbg & 16)) read_b16(rs, 1, F1b);
-                if (!(dbg & 2)) mfma16_block(Fa, F0b, std::integral_constant<int, 0>{});
+                if (dbg & 8192) __builtin_amdgcn_s_setprio(1);
+                if (!(dbg & 2)) mfma16_block(Fa, F0b, std::integral_constant<int, 0>{}, [&](int grp) {
+                    if constexpr (SPREAD) {
+                        if (!(dbg & 1)) {
+                            // grp is a compile-time constant after unrolling; the pieces go out in front of groups 0 .. NPT-1
+#define WT_PIECE(I) if (NPT > I && grp == I) load_piece(ws, std::integral_constant<int, (NPT > I ? I : 0)>{});
+                            WT_PIECE(0) WT_PIECE(1) WT_PIECE(2) WT_PIECE(3) WT_PIECE(4) WT_PIECE(5)
+                            WT_PIECE(6) WT_PIECE(7) WT_PIECE(8) WT_PIECE(9) WT_PIECE(10) WT_PIECE(11)
+#undef WT_PIECE
+                        }
+                    }
+                });
+                if (dbg & 8192) __builtin_amdgcn_s_setprio(0);
+                if (SPREAD && !(dbg & 1)) load_advance();
             } else {
                 if (!(dbg & 16)) read_frags(rs, 1, F1);
                 if (!(dbg & 2)) mfma_block(F0);
             }
-            if (!(dbg & 32)) wait_vm_lgkm<(NSTAGE - 2) * NPT>();
+            if (dbg & 32768) { if (!(dbg & 32)) wait_vm_lgkm<63>(); }                 // timing experiment: DMA issued, never waited for (races)
+            else if (!(dbg & 32)) wait_vm_lgkm<(NSTAGE - 2) * NPT>();
             if (!(dbg & 8)) __builtin_amdgcn_s_barrier();
             rs = rs + 1 == NSTAGE ? 0 : rs + 1;
             ws = ws + 1 == NSTAGE ? 0 : ws + 1;
             if (MF) {
                 if (!(dbg & 16)) read_b16(rs, 0, F0b);       // after the very last step: a harmless read of a zero-filled stage
-                if (!(dbg & 2)) mfma16_block(Fa, F1b, std::integral_constant<int, 1>{});
+                if (dbg & 8192) __builtin_amdgcn_s_setprio(1);
+                if (!(dbg & 2)) mfma16_block(Fa, F1b, std::integral_constant<int, 1>{}, [](int) {});
+                if (dbg & 8192) __builtin_amdgcn_s_setprio(0);
                 if (!(dbg & 16)) read_a16(rs, Fa);
             } else {
                 if (!(dbg & 16)) read_frags(rs, 0, F0);
@@ -625,7 +715,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
                             if (EPI == EPI_BIAS_ELU || (OUT == OUT_S32_DUAL_ELU && pz == 1)) {
                                 v.x = elu_s(v.x); v.y = elu_s(v.y); v.z = elu_s(v.z); v.w = elu_s(v.w);
                             } else if (EPI == EPI_BIAS_GELU) {
-                                v = gelu_erf_s4(v);
+                                v = (dbg & 16384) ? gelu_erf_s4(v) : gelu_erfc_s4(v);
                             }
                             if (as_f32) {
                                 *reinterpret_cast<f32x4*>(sc + rw * 128 + (((cw >> 2) ^ sww) * 16)) = v;
@@ -653,7 +743,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
                             const int n = n0 + 4 * ch;             // fp32 columns; S32: byte ch * 16 of the group at n0
                             if (m < p.M && (!as_f32 || n < p.N) && !(dbg & 128)) {
                                 float* dst = dbase + (long)m * p.c_rstride + n;
-                                *reinterpret_cast<f32x4*>(dst) = q[it];
+                                store_c16<!(dbg & 4096)>(dst, q[it]);
                             }
                         }
                     }
@@ -686,13 +776,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
                     } else if (EPI == EPI_BIAS_ELU) {
                         v.x = elu_s(v.x); v.y = elu_s(v.y); v.z = elu_s(v.z); v.w = elu_s(v.w);
                     } else if (EPI == EPI_BIAS_GELU) {
-                        v = gelu_erf_s4(v);
+                        v = (dbg & 16384) ? gelu_erf_s4(v) : gelu_erfc_s4(v);
                     } else if (EPI == EPI_BIAS_GAMMA_RES) {
                         const f32x4 gm = *reinterpret_cast<const f32x4*>(pcw + WN * 4 + (n - n_w) * 4);      // EPI_BIAS_GAMMA_RES: always cached
                         v = *reinterpret_cast<const f32x4*>(p.R + (long)m * p.r_rstride + n) + gm * v;
                     }
                     if (OUT == OUT_S32 || OUT == OUT_S32_DUAL_ELU) store_s32_x4(crow, n, v, amax);
-                    else *reinterpret_cast<f32x4*>(crow + n) = v;
+                    else store_c16<(dbg & 262144) != 0>(crow + n, v);
                     if (OUT == OUT_S32_DUAL_ELU) {
                         f32x4 ev;
                         ev.x = elu_s(v.x); ev.y = elu_s(v.y); ev.z = elu_s(v.z); ev.w = elu_s(v.w);
@@ -771,7 +861,7 @@ int launch_pow2_scales(const float* a, long na, const float* b, long nb, unsigne
 }
 
 // ---------------------------------------------------------------------------------- host side
-template <int BM, int BN, int WMs, int WNs, int NSTAGE, int EPI, int OUT, int WPS = 2>
+template <int BM, int BN, int WMs, int WNs, int NSTAGE, int EPI, int OUT, int WPS = 2, int LABDBG = 0>
 static int launch16s_one(const GemmArgs& a, hipStream_t s) {
     static PerDeviceOnce attr_once;
     constexpr size_t stage_bytes = (size_t)NSTAGE * (BM + BN) * 128;
@@ -782,10 +872,10 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
     static_assert(stage_bytes + 2 * BM * sizeof(unsigned) <= smem_cap, "LDS budget");
     if (smem > smem_cap) { set_error("gemm16s: too many taps for this tile's LDS budget"); return -1; }
     using kern_t = void (*)(const GemmArgs);
-    kern_t kern = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 0, WT_GEMM16S_MF, WPS>;
+    kern_t kern = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, LABDBG, WT_GEMM16S_MF, WPS>;
     // the timing-experiment builds exist for the tile the ConvNeXt GEMMs run on (tools/gemm16s_bench.py dbg): the masks of
     // the ablation ladder, each also with the clock stamps (+1024)
-    constexpr bool has_dbg = BM == 128 && BN == 192 && (WMs == 4 || WPS == 1) && NSTAGE == 3 && ((EPI == EPI_BIAS && OUT == OUT_F32) || (EPI == EPI_BIAS_GELU && OUT == OUT_S32));
+    constexpr bool has_dbg = LABDBG == 0 && BM == 128 && BN == 192 && WMs == 4 && NSTAGE == 3 && ((EPI == EPI_BIAS && OUT == OUT_F32) || (EPI == EPI_BIAS_GELU && OUT == OUT_S32));
     int dbg_req = 0;
     if (const char* e = getenv("WT_GEMM16S_DBG")) dbg_req = atoi(e);
     kern_t dbg_kerns[8] = {};
@@ -806,7 +896,7 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
         }
     }
     if (int rc = attr_once.run([&]() -> int {
-        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, 0, WT_GEMM16S_MF, WPS>),
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, LABDBG, WT_GEMM16S_MF, WPS>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max));
         for (int i = 0; i < 8; ++i)
             if (dbg_kerns[i]) WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dbg_kerns[i]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max));
@@ -860,6 +950,7 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
     return 0;
 }
 
+#ifndef WT_GEMM16S_LAB      // tools/micro/gemm_lab.hip includes this file and instantiates the variants it compares itself
 static int tile16s_override() {
     const char* e = getenv("WT_GEMM16S_TILE");      // read per launch: tools/gemm16s_bench.py switches it in-process
     return e ? atoi(e) : -1;
@@ -873,15 +964,10 @@ static int launch16s_tiled(const GemmArgs& a, hipStream_t s) {
         return launch16s_one<128, 192, 4, 2, 3, EPI, OUT>(a, s);      // gemm16s_vq_parts() assumes this tile
     } else {
         switch (tile16s_override()) {       // experiment hook (tools/linear_bench.py)
-            case 1: return launch16s_one<128, 96, 4, 1, 2, EPI, OUT>(a, s);
             case 2: return launch16s_one<128, 192, 4, 2, 3, EPI, OUT>(a, s);
             case 3: return launch16s_one<128, 128, 4, 2, 3, EPI, OUT>(a, s);
-            case 5: return launch16s_one<128, 128, 4, 2, 4, EPI, OUT>(a, s);
-            case 6: return launch16s_one<128, 192, 4, 2, 2, EPI, OUT>(a, s);
-            case 7: return launch16s_one<256, 128, 4, 2, 3, EPI, OUT>(a, s);
             case 8: return launch16s_one<128, 32, 4, 1, 3, EPI, OUT>(a, s);
             case 9: return launch16s_one<128, 64, 4, 1, 3, EPI, OUT>(a, s);
-            case 10: return launch16s_one<128, 192, 2, 2, 3, EPI, OUT, 1>(a, s);     // 4 waves, one per SIMD, 512 registers
             default: break;
         }
         if (a.N <= 64) return launch16s_one<256, 64, 8, 1, 3, EPI, OUT>(a, s);      // narrow outputs (down conv 1)
@@ -961,5 +1047,6 @@ int launch_gemm16s(const GemmArgs& a_in, int epi, int out, hipStream_t s) {
     set_error("gemm16s: unsupported epilogue / output-format pair");
     return -1;
 }
+#endif      // WT_GEMM16S_LAB
 
 }  // namespace wt

@@ -274,6 +274,7 @@ size_t model_export_bytes(const wt_model* M);
 int model_export(const wt_model* M, void* buf, size_t n);
 int model_import(wt_model* M, const void* buf, size_t n);        // M->device set; allocates and uploads
 int packed_info(const void* buf, size_t n, wt_arch* arch, int32_t* version, uint64_t* arch_hash);
+size_t packed_bytes(const void* buf, size_t n);                  // exact length of the image at buf (0: bad header)
 int packed_verify(const void* buf, size_t n);                    // header + bounds + content hash; needs no GPU
 // plan.cpp
 struct SConvGeom { int pl, pr_total, Tout, Tp; };

@@ -1050,7 +1050,9 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(const LstmAr
     const int t = s - layer;                        // time step this block advances
     if (t < 0 || t >= L) return;                    // uniform per block
     const int b0 = blockIdx.y * 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave index as a scalar: the K-slice bases it selects (weights, state) then live in SGPRs (the kernel is capped at
+    // 128 VGPRs by its 1024 threads and spilled 12 with them in vector registers)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, lk = lane >> 4;
 
     const int Ktot = layer ? 2 * H : H;
@@ -1090,20 +1092,26 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(const LstmAr
     for (int e = 0; e < 4; ++e) acc[e] = (f32x4acc){0.f, 0.f, 0.f, 0.f};
     f32x4 wv[LSTM_MAXS], hv[4 * LSTM_MAXS];
     const int nS = kw / 16;                         // 16-k groups: 2 or 4; k-steps: 4 per group
+    // groups [S0, S1) of the slice into registers.  fp32: everything at once (one L2 round trip).  f16: one 32-k block per
+    // batch: the second accumulator set of the split-f16 form leaves no room for 80 operand registers under the 128-VGPR cap
+    // of a 1024-thread workgroup (the whole-slice batch spilled 12 registers)
+    auto load_groups = [&](int S0, int S1) {
 #pragma unroll
-    for (int S = 0; S < LSTM_MAXS; ++S) {
-        if (S < nS) {
-            if (dbg & 2) {
-                wv[S] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int S = 0; S < LSTM_MAXS; ++S) {
+            if (S >= S0 && S < S1 && S < nS) {
+                if (dbg & 2) {
+                    wv[S] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) hv[4 * S + q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                continue;
+                    for (int q = 0; q < 4; ++q) hv[4 * S + q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    continue;
+                }
+                wv[S] = *reinterpret_cast<const f32x4*>(W + S * 256);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hv[4 * S + q] = *reinterpret_cast<const f32x4*>(hp + (long)(4 * (4 * S + q)) * Bp);
             }
-            wv[S] = *reinterpret_cast<const f32x4*>(W + S * 256);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) hv[4 * S + q] = *reinterpret_cast<const f32x4*>(hp + (long)(4 * (4 * S + q)) * Bp);
         }
-    }
+    };
+    if constexpr (!F16) load_groups(0, LSTM_MAXS);
     if constexpr (!F16) {
 #pragma unroll
         for (int S = 0; S < LSTM_MAXS; ++S) {
@@ -1122,6 +1130,7 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(const LstmAr
 #pragma unroll
         for (int P = 0; P < LSTM_MAXS / 2; ++P) {
             if (2 * P < nS) {
+                load_groups(2 * P, 2 * P + 2);
                 // weights of block P: wv[2P] = hi halves of the lane's 8 k, wv[2P+1] = lo halves
                 const f16x8l wh = __builtin_bit_cast(f16x8l, wv[2 * P]), wl = __builtin_bit_cast(f16x8l, wv[2 * P + 1]);
 #pragma unroll

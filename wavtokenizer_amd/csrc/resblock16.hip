@@ -268,6 +268,11 @@ __global__ __launch_bounds__(ROWS / FPW * 64, DOWN ? 2 : 1) void resblock16_kern
 #pragma unroll
         for (int i = 0; i < 4; ++i) bd4[i] = a.bd[16 * wave + 4 * q + i];
     }
+    // The weights' range is reported NOW: left to the end of the kernel, hipcc kept every raw fp32 weight register (about 80 of
+    // them with the down conv's) alive across the whole tile loop just to take their maximum there (256 VGPRs + 16 spilled;
+    // the asm makes the maximum opaque, so it has to be formed here)
+    asm volatile("" : "+v"(wmax));
+    range_report(a.status, wmax);
 
     const int fl = lane & 31, fh = lane >> 5;        // MFMA lane: (row or column fl, k half fh)
     const int row0 = wave * FPW;                     // this wave's frames inside the tile
@@ -664,7 +669,7 @@ __global__ __launch_bounds__(ROWS / FPW * 64, DOWN ? 2 : 1) void resblock16_kern
         ti += (int)gridDim.x;
         while (ti >= tiles_per_clip) { ti -= tiles_per_clip; ++b; }
     }
-    range_report(a.status, fmaxf(amax, wmax));
+    range_report(a.status, amax);
 }
 
 template <int C, int ROWS, int FOLD, int FPW = 32>

@@ -706,6 +706,14 @@ int packed_info(const void* buf, size_t n, wt_arch* arch, int32_t* version, uint
     return WT_OK;
 }
 
+// length of the image that starts at buf (wt_model_export_bytes is an upper bound taken before the model section is written)
+size_t packed_bytes(const void* buf, size_t n) {
+    if (packed_info(buf, n, nullptr, nullptr, nullptr)) return 0;
+    PackHeader h;
+    std::memcpy(&h, buf, sizeof(h));
+    return (sizeof(PackHeader) + h.n_allocs * 8 + h.struct_bytes + 255) / 256 * 256 + h.payload_bytes;
+}
+
 // full check of an image that needs no GPU: header, table and section bounds, and the hash of everything behind the header
 int packed_verify(const void* buf, size_t n) {
     if (int rc = packed_info(buf, n, nullptr, nullptr, nullptr)) return rc;

@@ -215,7 +215,8 @@ class _Engine:
         n = lib.wt_model_export_bytes(self.model)
         buf = np.empty(n, dtype=np.uint8)
         check(lib.wt_model_export(self.model, buf.ctypes.data_as(ctypes.c_void_p), n), "wt_model_export")
-        return buf
+        used = lib.wt_packed_bytes(buf.ctypes.data_as(ctypes.c_void_p), n)       # wt_model_export_bytes is an upper bound
+        return buf[:used] if 0 < used <= n else buf
 
     def plan(self, kind: int, B: int, length: int, flags: int, device: torch.device):
         key = (kind, B, length, flags)
@@ -281,6 +282,7 @@ class WavTokenizer(nn.Module):
         self._check_codes = {"1": "deferred", "0": "off"}.get(os.environ.get("WAVTOK_CHECK_CODES", "deferred"),
                                                               os.environ.get("WAVTOK_CHECK_CODES", "deferred"))
         self._bw_cache = None                # (tensor ref, version, index): bandwidth_id tensors living on the GPU
+        self.fallback_events: List[str] = []   # device-side failures this model has answered by falling back (check_status reports them)
         # batches up to this many clips are replayed as one hipGraph per (shape) plan: they are bound by the host's
         # launch rate (about 100 launches per call), not by the GPU; 0 turns graphs off
         self._graph_max_clips = int(os.environ.get("WAVTOK_GRAPH_MAX_CLIPS", "16"))
@@ -473,25 +475,29 @@ class WavTokenizer(nn.Module):
         self._strict = bool(on)
 
     def check_status(self):
-        """Synchronise and raise WavTokError if any call since the last check failed on the device."""
+        """Synchronise and raise WavTokError if any call since the last check failed on the device: failures still pending
+        in the status words, and failures that a later call has already consumed and answered by falling back
+        (self.fallback_events; in non-strict mode the failed call's poisoned outputs were handed out)."""
         dev = self._device()
         torch.cuda.current_stream(dev).synchronize()
-        bad = []
+        # the model's word first: it is what decides (every plan's guard step reports into it, and it outlives plans the
+        # LRU has destroyed); the plans' own words only say which plans reported since the last check and may hold
+        # failures that a later call has already consumed and answered by falling back
+        mbits = ctypes.c_int32()
+        if self._engine.model:
+            check(lib.wt_model_status(self._engine.model, ctypes.byref(mbits), 1), "wt_model_status")
+        seen = []
         for key, (plan, _ws) in self._engine.plans.items():
             bits = ctypes.c_int32()
             check(lib.wt_plan_status(plan, ctypes.byref(bits), 1), "wt_plan_status")
             if bits.value:
-                bad.append((key, bits.value))
-                if bits.value & _capi.WT_STATUS_BIT_RANGE:
-                    self._plan_flags |= _capi.WT_PLAN_FLAG_FP32_GEMM
-        mbits = ctypes.c_int32()
-        if self._engine.model:
-            # the model's own word: failures of plans that the LRU has destroyed since are still recorded there
-            check(lib.wt_model_status(self._engine.model, ctypes.byref(mbits), 1), "wt_model_status")
-            if mbits.value & _capi.WT_STATUS_BIT_RANGE:
-                self._plan_flags |= _capi.WT_PLAN_FLAG_FP32_GEMM
-            if mbits.value and not bad:
-                bad.append(("model", mbits.value))
+                seen.append((key, bits.value))
+        if mbits.value & _capi.WT_STATUS_BIT_RANGE:
+            self._plan_flags |= _capi.WT_PLAN_FLAG_FP32_GEMM
+        bad = (seen or [("model", mbits.value)]) if mbits.value else []
+        events, self.fallback_events = self.fallback_events, []
+        if events and not bad:
+            raise WavTokError("device-side failures since the last check, already answered by a fallback: %s" % events)
         self._poll_bad_codes()
         if bad:
             raise WavTokError("device-side failure in earlier calls (plan key, status bits): %s; their outputs were "
@@ -534,8 +540,12 @@ class WavTokenizer(nn.Module):
                 out = launch(plan, ws)
             except WavTokError as e:
                 if e.status == _capi.WT_ERR_LSTM_SYNC and attempt < 2:
-                    continue                                  # the plan now runs the step LSTM
+                    self.fallback_events.append("persistent LSTM lost co-residency in an earlier call (its outputs were poisoned): "
+                                                "the model now runs the launch-per-step LSTM")
+                    continue                                  # the model's plans now run the step LSTM
                 if e.status == _capi.WT_ERR_RANGE and attempt < 2:
+                    self.fallback_events.append("an earlier call left the f16 range of the split-f16 form (its outputs were "
+                                                "poisoned): the model now runs fp32 GEMMs")
                     self._plan_flags |= _capi.WT_PLAN_FLAG_FP32_GEMM
                     continue
                 raise
@@ -546,6 +556,7 @@ class WavTokenizer(nn.Module):
             check(lib.wt_plan_status(plan, ctypes.byref(bits), 1), "wt_plan_status")
             if not bits.value:
                 return out
+            self.fallback_events.append("strict mode: the call failed on the device (status bits %d) and was repeated on the fallback path" % bits.value)
             if bits.value & _capi.WT_STATUS_BIT_RANGE:
                 self._plan_flags |= _capi.WT_PLAN_FLAG_FP32_GEMM
         raise WavTokError("the call kept failing on the device after the fp32 / step-LSTM fallbacks")
