@@ -87,10 +87,15 @@ int main(int argc, char** argv) {
                   {"  r03 without DMA spread", run128x192<EPI_BIAS_GELU, OUT_S32, 2048>},
                   {"  r03 without sc1 stores", run128x192<EPI_BIAS_GELU, OUT_S32, 4096>},
                   {"  r03 with the two-branch GELU", run128x192<EPI_BIAS_GELU, OUT_S32, 16384>},
+                  {"  r03 with GELU one sub-run at a time", run128x192<EPI_BIAS_GELU, OUT_S32, 524288>},
                   {"  r03 with a vector wave id", run128x192<EPI_BIAS_GELU, OUT_S32, 65536>},
                   {"  r03 + setprio", run128x192<EPI_BIAS_GELU, OUT_S32, 8192>},
+                  {"epilogue without GELU", run128x192<EPI_BIAS_GELU, OUT_S32, 512>},
+                  {"epilogue without global stores", run128x192<EPI_BIAS_GELU, OUT_S32, 128>},
+                  {"epilogue without GELU and stores", run128x192<EPI_BIAS_GELU, OUT_S32, 512 + 128>},
                   {"no epilogue", run128x192<EPI_BIAS_GELU, OUT_S32, 4>},
                   {"no epilogue, DMA fetches nothing", run128x192<EPI_BIAS_GELU, OUT_S32, 4 + 131072>},
+                  {"no epilogue, DMA re-reads one 8 KB window", run128x192<EPI_BIAS_GELU, OUT_S32, 4 + 1048576>},
                   {"no epilogue, no DMA", run128x192<EPI_BIAS_GELU, OUT_S32, 5>}};
         } else {
             vs = {{"r02 structure", run128x192<EPI_BIAS_GAMMA_RES, OUT_F32, 65536 + 2048>},

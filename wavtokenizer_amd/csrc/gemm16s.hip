@@ -118,6 +118,41 @@ __device__ __forceinline__ f32x4 gelu_erfc_s4(f32x4 v) {
     const f32x2 lo = gelu_erfc_s2((f32x2){v.x, v.y}), hi = gelu_erfc_s2((f32x2){v.z, v.w});
     return (f32x4){lo.x, lo.y, hi.x, hi.y};
 }
+// The same arithmetic on the four sub-runs of a 32 x 32 block at once, written step by step ACROSS the eight packed pairs:
+// a packed fp32 instruction that reads the result of the one in front of it costs a wait state (hipcc pads with s_nop), so
+// one Horner chain at a time runs at half rate; eight independent chains need no padding (same results bit for bit)
+__device__ __forceinline__ void gelu_erfc_x16(f32x4 (&v)[4]) {
+    f32x2 x[8], a[8], t[8], p[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        x[i] = (f32x2){v[i >> 1][2 * (i & 1)], v[i >> 1][2 * (i & 1) + 1]};
+        a[i] = x[i] * 0.70710678118654752440f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        t[i] = __builtin_elementwise_abs(a[i]);
+        t[i].x = fminf(t[i].x, 4.3f); t[i].y = fminf(t[i].y, 4.3f);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p[i] = fma2((f32x2)(1.146792511e-05f), t[i], (f32x2)(-1.515573094e-04f));
+    constexpr float c[8] = {8.423082181e-04f, -2.261521295e-03f, 6.768874300e-05f, 2.773740143e-02f, -1.483134478e-01f,
+                            -9.184416533e-01f, -1.627907395e+00f, -1.0f};
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p[i] = fma2(p[i], t[i], (f32x2)(c[s]));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        f32x2 h, sgn;
+        h.x = __builtin_amdgcn_exp2f(p[i].x);
+        h.y = __builtin_amdgcn_exp2f(p[i].y);
+        sgn.x = a[i].x >= 0.f ? 1.f - h.x : h.x;
+        sgn.y = a[i].y >= 0.f ? 1.f - h.y : h.y;
+        const f32x2 r = x[i] * sgn;
+        v[i >> 1][2 * (i & 1)] = r.x;
+        v[i >> 1][2 * (i & 1) + 1] = r.y;
+    }
+}
 
 // fp32 value -> S32 slots of element n (n & 31 = slot) in the group that starts at `grp` (a _Float16*)
 __device__ __forceinline__ void store_s32(_Float16* grp, int slot, float v) {
@@ -323,7 +358,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
         if constexpr (idx < NPA) {
             // the K advance rides in the instruction's scalar offset (it is not part of the range check, which the
             // out-of-range marker in the vector offset still fails): no vector add per piece
-            if (p.A2 && kL >= p.K1)
+            if (dbg & 1048576)      // timing experiment: real (non-zero) data, but always the same 8 KB: the cost of the traffic itself
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(sbase + NW * idx * 1024), 16, (int)(a_voff[idx] & 0x1fffu), 0, 0, 0);
+            else if (p.A2 && kL >= p.K1)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr_t)(sbase + NW * idx * 1024), 16,
                                                          (int)(a2_voff[idx] | l_mask), (kL - p.K1) * 4, 0, 0);
             else
@@ -331,6 +368,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
                                                          (int)(a_voff[idx] | l_mask), ciL * 4, 0, 0);
         } else {
             constexpr int j = idx - NPA;
+            if (dbg & 1048576)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(sbase + (BM / 8 + NW * j) * 1024), 16, (int)(w_voff[j] & 0x1fffu), 0, 0, 0);
+            else
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(sbase + (BM / 8 + NW * j) * 1024), 16,
                                                      (int)(w_voff[j] | l_mask), kL * 4, 0, 0);
         }
@@ -706,16 +746,26 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
                             if (p.bias && n < p.N && !(dbg & 256))
                                 bq[g] = PCACHE ? *reinterpret_cast<const f32x4*>(pcw + (n - n_w) * 4) : *reinterpret_cast<const f32x4*>(p.bias + n);
                         }
+                        f32x4 vb[4];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) vb[g] = acc4(i, j, g) + bq[g];
+                        if (EPI == EPI_BIAS_GELU && !(dbg & 512)) {
+                            if (dbg & 16384) {
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) vb[g] = gelu_erf_s4(vb[g]);
+                            } else if (dbg & 524288) {
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) vb[g] = gelu_erfc_s4(vb[g]);
+                            } else {
+                                gelu_erfc_x16(vb);
+                            }
+                        }
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const int rw = sub_row(g), cw = sub_col(g), sww = (rw >> 1) & 7;
-                            f32x4 v = acc4(i, j, g) + bq[g];
-                            if (EPI == EPI_BIAS_GELU && (dbg & 512)) {
-                            } else
+                            f32x4 v = vb[g];
                             if (EPI == EPI_BIAS_ELU || (OUT == OUT_S32_DUAL_ELU && pz == 1)) {
                                 v.x = elu_s(v.x); v.y = elu_s(v.y); v.z = elu_s(v.z); v.w = elu_s(v.w);
-                            } else if (EPI == EPI_BIAS_GELU) {
-                                v = (dbg & 16384) ? gelu_erf_s4(v) : gelu_erfc_s4(v);
                             }
                             if (as_f32) {
                                 *reinterpret_cast<f32x4*>(sc + rw * 128 + (((cw >> 2) ^ sww) * 16)) = v;

@@ -26,13 +26,18 @@ typedef _Float16 f16x8p __attribute__((ext_vector_type(8)));
 
 static constexpr int PW = 12;                      // waves per workgroup: 3 roles x 4 gate tiles
 static constexpr int HROW = 2 * 2048;              // staged state row: [layer 0 | layer 1], each 512 k in S32 (2048 B)
-static constexpr int HPITCH = HROW + 64;           // LDS row pitch (2-way instead of 16-way bank conflicts)
-static constexpr long SPIN_LIMIT = 1L << 22;
+static constexpr int HPITCH = HROW;                // LDS row pitch: no padding, the 16-byte chunks of a row are XOR-swizzled instead
+// Chunk swizzle of the staged state.  Every product wave reads the whole state tile once per step (12 waves x 16 KB), which
+// paces the product phase, and a ds_read_b128 is served in four NON-contiguous 16-lane groups (lanes 0-3, 12-15, 20-27 ...):
+// with the padded pitch of round 2 each group hit every bank twice (36 % of the LDS cycles were conflicts).  Chunk c of clip
+// row r is stored at c ^ lp_swz(r): SMALL (rows 0-7; a group reads hi chunks of four rows and lo chunks of the other four)
+// 2 r, else (16 rows, one chunk per group) r: every group then covers all 64 banks (tools/lds_banks.py)
+template <bool SMALL> __device__ __forceinline__ int lp_swz(int row) { return (SMALL ? 2 * row : row) & 15; }
 static constexpr long SPIN_LIMIT_DF = 1L << 20;    // polls of the state itself (about a microsecond each)
 // lo-weight blocks kept in LDS instead of registers, and staged clip rows.  SMALL (at most 8 clips per XCD, e.g. B = 64): the
 // state tile needs 8 rows and one 4-register A operand per block (hi and lo rows packed, see the product phase), which leaves
 // room for a double-buffered operand; 7 blocks in LDS measured the same as 8 or 9
-template <bool SMALL> struct LpCfg { static constexpr int NLDS = SMALL ? 7 : 6, HROWS = SMALL ? 8 : 16; };
+template <bool SMALL> struct LpCfg { static constexpr int NLDS = SMALL ? 8 : 6, HROWS = SMALL ? 8 : 16, POLL = SMALL ? 3 : 1; };
 
 __device__ __forceinline__ float sigm_p(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float tanh_p(float x) {
@@ -50,21 +55,20 @@ __device__ __forceinline__ _Float16 no_mark(_Float16 v) {
     return __builtin_bit_cast(_Float16, (unsigned short)(b == 0xFFFFu ? 0x7E00u : b));
 }
 
-// DF (default): the state exchange carries its own readiness.  Three buffers per XCD; every (layer, clip, unit) half is
+// The state exchange carries its own readiness.  Three buffers per XCD; every (layer, clip, unit) half is
 // either the mark 0xFFFF or data: the step-s reader polls the DATA of step s-1 (buffer (s-1) % 3) until no mark is left,
 // a writer stores step s into buffer s % 3 and, one step ahead of need, re-marks its own slice of buffer (s+1) % 3 (last
 // read during step s-1, which every workgroup has finished once this one holds all of step s-1; the re-mark is acknowledged
 // by L2 before the step's data is stored, so whoever sees that data can never see the older contents again).  Per step
 // that is ONE L2 round trip on each side (store; load) instead of store -> acknowledge -> counter atomic -> poll -> load.
-// !DF: the arrival-counter form (two buffers), kept for comparison (WT_LSTM_PERSIST=2).
 // phase timestamps of workgroup 0 of XCD 0, steps 64..71 (WT_LSTM_TRACE=1, tools/lstm_trace.py): 100 MHz ticks into ctl[520..]
 #define LP_TRACE(ph) do { if (TRACE && tr_on && s >= 64 && s < 72) { \
     const unsigned long long tt = __builtin_amdgcn_s_memrealtime(); \
     if (lane == 0) { a.ctl[520 + ((s - 64) * 6 + (ph)) * 2] = (unsigned)tt; a.ctl[521 + ((s - 64) * 6 + (ph)) * 2] = (unsigned)(tt >> 32); } } } while (0)
 // TRACE: the phase-timestamp build (WT_LSTM_TRACE=1); the shipped instantiations carry no run-time test for it
-template <bool DF, bool SMALL, bool TRACE = false>
+template <bool SMALL, bool TRACE = false>
 __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersistArgs a) {
-    constexpr int NBUF = DF ? 3 : 2;
+    constexpr int NBUF = 3;
     constexpr int NLDS = LpCfg<SMALL>::NLDS, HROWS = LpCfg<SMALL>::HROWS;
     extern __shared__ __attribute__((aligned(16))) char sm_p[];
     char* hst = sm_p;                                                   // [HROWS clips][HPITCH]
@@ -78,8 +82,8 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
     if (tid == 0) {
         const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7;          // HW_REG_XCC_ID[3:0]
         s_xcc = xcc;
-        // DF: the control block starts as all-ones like the state buffers (one memset), so the first ticket is ~0u + 1
-        s_w = __hip_atomic_fetch_add(a.ctl + xcc * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + (DF ? 1u : 0u);
+        // the control block starts as all-ones like the state buffers (one memset), so the first ticket is ~0u + 1
+        s_w = __hip_atomic_fetch_add(a.ctl + xcc * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u;
         s_stop = 0;
     }
     __syncthreads();
@@ -89,7 +93,6 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
     const int c0g = xcc * a.Bx;
     const int nb = B - c0g < a.Bx ? B - c0g : a.Bx;      // clips of this XCD
     if (nb <= 0) return;                                 // uniform over the XCD's workgroups
-    unsigned* cnt = a.ctl + 256 + xcc * 32;              // this XCD's arrival counter (own cache line)
     unsigned* err = a.ctl + 512;
     char* hx = reinterpret_cast<char*>(a.hx) + (size_t)xcc * (NBUF * 2 * 16 * 2048);    // [buffer][layer][clip][2048 B]
     const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(hx, 0, NBUF * 2 * 16 * 2048, 0x00020000);
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
     __syncthreads();
     // the spin bounds; a test hook (LstmPersistArgs::dbg_spin_shift) shortens them so that a forced loss of co-residency
     // is reported within milliseconds
-    const long spin_limit = SPIN_LIMIT >> a.dbg_spin_shift, spin_limit_df = SPIN_LIMIT_DF >> a.dbg_spin_shift;
+    const long spin_limit_df = SPIN_LIMIT_DF >> a.dbg_spin_shift;
     const bool tr_on = TRACE && xcc == 0 && w == 0 && __builtin_amdgcn_readfirstlane(wave) == 0;
     for (int s = 0; s <= L; ++s) {
         LP_TRACE(0);
@@ -134,17 +137,18 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
             for (int g = 0; g < 4; ++g) xg[g] = a.b1[64 * w + 16 * c_nt + g * 4 + c_u4];     // layer 1: its bias (an L1 hit; no registers held across steps)
         }
 
-        if (DF) {
+        {
             // 1+2. poll the state of step s-1 itself (L2 loads that skip the CU's L1) until every half is data, then
             //      stage it in LDS; h0[-1] = h1[-1] = 0 are not loaded (layer 1 runs one step behind: its first
             //      state appears in buffer 1)
             const int rb = (s + 2) % 3, tot = 2 * nb * 128;
-            // up to 16 clips: 4096 chunks = 6 per thread, polled three at a time (the weights leave 12 free registers)
-            for (int e0 = tid; e0 < tot; e0 += 3 * 64 * PW) {
-                f32x4p v[3];
+            // up to 16 clips: 4096 chunks = 6 per thread, polled POLL at a time (what the resident weights leave free)
+            constexpr int POLL = LpCfg<SMALL>::POLL;
+            for (int e0 = tid; e0 < tot; e0 += POLL * 64 * PW) {
+                f32x4p v[POLL];
                 unsigned need = 0;
 #pragma unroll
-                for (int it = 0; it < 3; ++it) {
+                for (int it = 0; it < POLL; ++it) {
                     const int e = e0 + it * 64 * PW;
                     if (e < tot && s >= 1 + (e >> 7) / nb) need |= 1u << it;
                 }
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
                 long spin = 0;
                 while (pend) {
 #pragma unroll
-                    for (int it = 0; it < 3; ++it)
+                    for (int it = 0; it < POLL; ++it)
                         if (pend >> it & 1) {
                             const int e = e0 + it * 64 * PW;
                             const int c16 = e & 127, lc = e >> 7, layer = lc / nb, clip = lc - layer * nb;
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
                         }
                     unsigned still = 0;
 #pragma unroll
-                    for (int it = 0; it < 3; ++it)
+                    for (int it = 0; it < POLL; ++it)
                         if (pend >> it & 1) {
                             const unsigned m = has_mark(__builtin_bit_cast(unsigned, v[it].x)) | has_mark(__builtin_bit_cast(unsigned, v[it].y)) |
                                                has_mark(__builtin_bit_cast(unsigned, v[it].z)) | has_mark(__builtin_bit_cast(unsigned, v[it].w));
@@ -179,11 +183,11 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
                     }
                 }
 #pragma unroll
-                for (int it = 0; it < 3; ++it) {
+                for (int it = 0; it < POLL; ++it) {
                     const int e = e0 + it * 64 * PW;
                     if (e < tot) {
                         const int c16 = e & 127, lc = e >> 7, layer = lc / nb, clip = lc - layer * nb;
-                        *reinterpret_cast<f32x4p*>(hst + clip * HPITCH + layer * 2048 + c16 * 16) =
+                        *reinterpret_cast<f32x4p*>(hst + clip * HPITCH + layer * 2048 + ((c16 ^ lp_swz<SMALL>(clip)) * 16)) =
                             (need >> it & 1) ? v[it] : (f32x4p){0.f, 0.f, 0.f, 0.f};
                     }
                 }
@@ -199,38 +203,6 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
                 mrow[(j >> 5) * 64 + (j & 31)] = 0xFFFFu;
                 mrow[(j >> 5) * 64 + 32 + (j & 31)] = 0xFFFFu;
             }
-        } else {
-        // 1. everybody on this XCD has published step s-1
-        if (s > 0) {
-            if (tid == 0) {
-                const unsigned want = 32u * (unsigned)s;
-                long spin = 0;
-                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                    if (++spin > spin_limit || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (a.status) __hip_atomic_fetch_or(a.status, (unsigned)WT_STATUS_LSTM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        s_stop = 1;
-                        break;
-                    }
-                }
-            }
-            __syncthreads();
-            if (s_stop) return;
-        }
-        // 2. stage the state of step s-1 (both layers, this XCD's 16 clip rows) from L2 into LDS, skipping the CU's L1
-        {
-            const int par = (s - 1) & 1;
-            // rows of clips >= nb are zero-filled once (below) and never restaged
-            for (int e = tid; e < 2 * nb * 128; e += 64 * PW) {
-                const int c16 = e & 127, lc = e >> 7, layer = lc / nb, clip = lc - layer * nb;
-                f32x4p v = {0.f, 0.f, 0.f, 0.f};
-                if (s > 0)
-                    v = __builtin_bit_cast(f32x4p, __builtin_amdgcn_raw_buffer_load_b128(
-                            rsH, ((par * 2 + layer) * 16 + clip) * 2048 + c16 * 16, 0, 16 /* sc1: miss the CU's L1, hit the XCD's L2 */));
-                *reinterpret_cast<f32x4p*>(hst + clip * HPITCH + layer * 2048 + c16 * 16) = v;
-            }
-        }
-        __syncthreads();
         }
         // 3. recurrent products: role 0: W_hh_l0 . h0[s-1] (layer 0, t = s); role 1: W_ih_l1 . h0[s-1]; role 2:
         //    W_hh_l1 . h1[s-2] (layer 1, t = s-1)
@@ -241,14 +213,20 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
                 // halves in rows 8-15, so ONE MFMA against W_hi yields the main term (rows 0-7) and the lo.W_hi correction
                 // (rows 8-15); a second one against W_lo yields the hi.W_lo correction in rows 0-7 (its rows 8-15 are the
                 // lo.lo term nobody needs): two MFMAs per block instead of three, one 16-byte LDS read per lane per block.
-                const char* ap = hst + (li & 7) * HPITCH + (role == 2 ? 2048 : 0) + lk * 16 + ((li & 8) ? 64 : 0);
+                // chunk (blk * 8 + 4 * lo + lk) ^ swizzle: the swizzle only touches the low four bits, blk * 8 toggles bit 3 and up
+                // (the swizzle touches the low four bits of the chunk index and blk * 8 toggles bit 3 and up, so the sixteen reads are
+                // two per-lane bases, even and odd blocks, plus immediates)
+                const int ach = (lk + ((li & 8) ? 4 : 0)) ^ lp_swz<SMALL>(li & 7);
+                const char* ap0 = hst + (li & 7) * HPITCH + (role == 2 ? 2048 : 0) + (ach & 7) * 16;
+                const char* ape = ap0 + (ach >> 3) * 128;           // blocks 0, 2, 4, ...: + (blk >> 1) * 256
+                const char* apo = ap0 + (1 ^ (ach >> 3)) * 128;     // blocks 1, 3, 5, ...
                 const bool arow = (li & 7) < nb;                   // absent clip rows stay zero and are not read
                 f32x4p accm = {0.f, 0.f, 0.f, 0.f}, accc = accm;
                 f16x8p a1b[2] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
-                if (arow) a1b[0] = *reinterpret_cast<const f16x8p*>(ap);
+                if (arow) a1b[0] = *reinterpret_cast<const f16x8p*>(ape);
 #pragma unroll
                 for (int blk = 0; blk < 16; ++blk) {
-                    if (blk + 1 < 16 && arow) a1b[(blk + 1) & 1] = *reinterpret_cast<const f16x8p*>(ap + (blk + 1) * 128);
+                    if (blk + 1 < 16 && arow) a1b[(blk + 1) & 1] = *reinterpret_cast<const f16x8p*>((((blk + 1) & 1) ? apo : ape) + ((blk + 1) >> 1) * 256);
                     const f16x8p a1 = a1b[blk & 1];
                     const f16x8p wlb = blk < 16 - NLDS ? wl[blk < 16 - NLDS ? blk : 0]
                                                        : __builtin_bit_cast(f16x8p, wlds[(blk - (16 - NLDS)) * 64]);
@@ -264,18 +242,25 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
                     if (lk < 2) gb[(4 * lk + r) * 17 + li] = accm[r] + (accc[r] + c2) * (1.f / 2048.f);
                 }
             } else if (act) {
-                const char* ap = hst + li * HPITCH + (role == 2 ? 2048 : 0) + lk * 16;
+                // hi chunk lk, lo chunk lk + 4 of every 8-chunk block, swizzled: the lo chunk is the hi chunk's address with bit 6
+                // flipped, an odd block's is an even block's with bit 7 flipped (rows are 4096-byte aligned)
+                const int ch_h = lk ^ lp_swz<SMALL>(li);
+                const char* ap0 = hst + li * HPITCH + (role == 2 ? 2048 : 0) + (ch_h & 7) * 16;
+                const char* ape = ap0 + (ch_h >> 3) * 128;
+                const char* apo = ap0 + (1 ^ (ch_h >> 3)) * 128;
+                const int lo_d = (ch_h & 4) ? -64 : 64;             // (chunk ^ 4) - chunk, in bytes
                 f32x4p accm = {0.f, 0.f, 0.f, 0.f}, accc = accm;
                 // the state reads of the twelve waves pace this phase: the next block's operand is requested before this
                 // block's MFMAs are issued
                 f16x8p ahb[2], alb[2];
-                ahb[0] = *reinterpret_cast<const f16x8p*>(ap);
-                alb[0] = *reinterpret_cast<const f16x8p*>(ap + 64);
+                ahb[0] = *reinterpret_cast<const f16x8p*>(ape);
+                alb[0] = *reinterpret_cast<const f16x8p*>(ape + lo_d);
 #pragma unroll
                 for (int blk = 0; blk < 16; ++blk) {
                     if (blk + 1 < 16) {
-                        ahb[(blk + 1) & 1] = *reinterpret_cast<const f16x8p*>(ap + (blk + 1) * 128);
-                        alb[(blk + 1) & 1] = *reinterpret_cast<const f16x8p*>(ap + (blk + 1) * 128 + 64);
+                        const char* pb = (((blk + 1) & 1) ? apo : ape) + ((blk + 1) >> 1) * 256;
+                        ahb[(blk + 1) & 1] = *reinterpret_cast<const f16x8p*>(pb);
+                        alb[(blk + 1) & 1] = *reinterpret_cast<const f16x8p*>(pb + lo_d);
                     }
                     const f16x8p ah = ahb[blk & 1], al = alb[blk & 1];
                     const f16x8p wlb = blk < 16 - NLDS ? wl[blk < 16 - NLDS ? blk : 0]
@@ -305,12 +290,12 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
             const float ig = sigm_p(pre[0]), fg = sigm_p(pre[1]), gg = tanh_p(pre[2]), og = sigm_p(pre[3]);
             cst = fg * cst + ig * gg;
             const float h = og * tanh_p(cst);
-            _Float16* hrow = reinterpret_cast<_Float16*>(hx + (((DF ? s % 3 : s & 1) * 2 + c_layer) * 16 + c_clip) * 2048);
+            _Float16* hrow = reinterpret_cast<_Float16*>(hx + (((s % 3) * 2 + c_layer) * 16 + c_clip) * 2048);
             const _Float16 hh = (_Float16)h;
             const _Float16 hl = (_Float16)((h - (float)hh) * 2048.f);
-            if (DF) __builtin_amdgcn_s_waitcnt(0);                      // the re-mark of this step is in L2
-            hrow[(j >> 5) * 64 + (j & 31)] = DF ? no_mark(hh) : hh;
-            hrow[(j >> 5) * 64 + 32 + (j & 31)] = DF ? no_mark(hl) : hl;
+            __builtin_amdgcn_s_waitcnt(0);                      // the re-mark of this step is in L2
+            hrow[(j >> 5) * 64 + (j & 31)] = no_mark(hh);
+            hrow[(j >> 5) * 64 + 32 + (j & 31)] = no_mark(hl);
             if (c_layer == 1) {
                 const int t = s - 1;
                 const float yv = h + xs;                                // lstm.py:37-38 skip
@@ -329,12 +314,6 @@ __global__ __launch_bounds__(64 * PW) void lstm_persist_kernel(const LstmPersist
             }
         }
         LP_TRACE(5);
-        if (!DF) {
-            // 5. publish: the stores are acknowledged by L2 before this workgroup arrives
-            __builtin_amdgcn_s_waitcnt(0);
-            __syncthreads();
-            if (tid == 0 && s < L) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
     }
 }
 
@@ -349,15 +328,13 @@ int launch_lstm_persist(const LstmPersistArgs& a, hipStream_t stream) {
     constexpr size_t smem_small = (size_t)8 * HPITCH + (size_t)3 * 4 * 16 * 17 * sizeof(float) + (size_t)PW * LpCfg<true>::NLDS * 1024;
     static_assert(smem_big + 64 <= 160 * 1024 && smem_small + 64 <= 160 * 1024, "LDS budget");
     if (int rc = attr_once.run([&]() -> int {
-        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_big));
-        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_big));
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_big));
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_small));
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_big));
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_small));
-        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_small));
-        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_big));
-        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_small));
         return 0;
     })) return rc;
-    // the caller has filled hx and ctl with 0xFF bytes (data-flag form) or zeros (counter form)
+    // the caller has filled hx and ctl with 0xFF bytes (the marks of the data-flag exchange)
     const bool small = a.Bx <= 8;
     LstmPersistArgs b = a;
     if (!b.status) b.status = g_launch.status;
@@ -369,14 +346,11 @@ int launch_lstm_persist(const LstmPersistArgs& a, hipStream_t stream) {
     if (forced) b.dbg_spin_shift = 8;
     const dim3 grid(forced ? 248 : 256), block(64 * PW);
     if (a.data_flag & 4) {          // phase timestamps (tools/lstm_trace.py)
-        if (small) hipLaunchKernelGGL((lstm_persist_kernel<true, true, true>), grid, block, smem_small, stream, b);
-        else hipLaunchKernelGGL((lstm_persist_kernel<true, false, true>), grid, block, smem_big, stream, b);
-    } else if (a.data_flag) {
         if (small) hipLaunchKernelGGL((lstm_persist_kernel<true, true>), grid, block, smem_small, stream, b);
-        else hipLaunchKernelGGL((lstm_persist_kernel<true, false>), grid, block, smem_big, stream, b);
+        else hipLaunchKernelGGL((lstm_persist_kernel<false, true>), grid, block, smem_big, stream, b);
     } else {
-        if (small) hipLaunchKernelGGL((lstm_persist_kernel<false, true>), grid, block, smem_small, stream, b);
-        else hipLaunchKernelGGL((lstm_persist_kernel<false, false>), grid, block, smem_big, stream, b);
+        if (small) hipLaunchKernelGGL((lstm_persist_kernel<true>), grid, block, smem_small, stream, b);
+        else hipLaunchKernelGGL((lstm_persist_kernel<false>), grid, block, smem_big, stream, b);
     }
     WT_HIP_CHECK(hipGetLastError());
     return 0;

@@ -153,11 +153,10 @@ static int plan_lstm(wt_plan* P, const LstmW& w, int B, int L, int H, int xin, c
     P->step({xin, xg, st, hx, y}, [=](const RunCtx& c) {
         if (persist && P->model->persist_ok.load()) {
             float* hb = P->ptr(c, hx);
-            static const bool counter_form = [] { const char* e = getenv("WT_LSTM_PERSIST"); return e && e[0] == '2'; }();
-            if (int rc = launch_fill_u32(hb, counter_form ? 0u : 0xFFFFFFFFu, (hxn + ctn) * sizeof(float), c.stream)) return rc;
+            if (int rc = launch_fill_u32(hb, 0xFFFFFFFFu, (hxn + ctn) * sizeof(float), c.stream)) return rc;
             LstmPersistArgs pa;
             static const int df_trace = [] { const char* e = getenv("WT_LSTM_TRACE"); return e ? atoi(e) : 0; }();
-            pa.data_flag = counter_form ? 0 : (1 | (df_trace ? 4 : 0));
+            pa.data_flag = 1 | (df_trace ? 4 : 0);
             pa.xg0 = P->ptr(c, xg); pa.Wp = w.Wp; pa.b1 = w.b1; pa.x = P->ptr(c, xin); pa.y = P->ptr(c, y);
             pa.hx = hb; pa.ctl = reinterpret_cast<unsigned*>(hb + hxn);
             pa.B = B; pa.L = L; pa.H = H; pa.Bx = (B + 7) / 8; pa.elu_out = elu_out ? 1 : 0; pa.out_s32 = y_s32 ? 1 : 0;
