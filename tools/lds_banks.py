@@ -52,10 +52,13 @@ def report(name, instr, addr_fn, variants):
 
 
 # ------------------------------------------------------------------------------- resblock16.hip, C = 32, ROWS = 128
+NEW = True          # False: round 2's layouts
+
+
 def row_off(r, ci, lo, nbytes=128):
-    """RbRow<32>::off: 128-byte rows, chunk c of row r at c ^ ((r >> 1) & 7)"""
+    """xe of the C = 32 kernel: 128-byte rows, chunk c of row r at c ^ (r & 7) (round 2: RbRow<32>::off, c ^ ((r >> 1) & 7))"""
     c = lo * 4 + (ci % 32) // 8
-    return r * nbytes + ((c ^ ((r >> 1) & 7)) * 16)
+    return r * nbytes + ((c ^ ((r & 7) if NEW else ((r >> 1) & 7))) * 16)
 
 
 def he_off(r, ci, lo):
@@ -67,13 +70,14 @@ def he_off(r, ci, lo):
 def xr_chunk_off(r, chunk, DOWN):
     if DOWN:
         o, j = r // DOWN, r % DOWN
-        g = ((o >> 1) ^ (j * (8 // DOWN))) & 7
+        g = ((o ^ (5 * j)) & 7) if NEW else (((o >> 1) ^ (j * (8 // DOWN))) & 7)
         return (j * (128 // DOWN) + o) * 128 + ((chunk ^ g) * 16)
     return r * 128 + ((chunk ^ ((r >> 1) & 7)) * 16)
 
 
 def woff(rows, ks, hl, n, h):
-    return ((ks * 2 + hl) * rows + n) * 32 + ((h ^ ((n >> 3) & 1)) * 16)
+    sw = 0 if (NEW and rows == 16) else ((n >> 3) & 1)
+    return ((ks * 2 + hl) * rows + n) * 32 + ((h ^ sw) * 16)
 
 
 def stage1(DOWN=4):
@@ -117,6 +121,9 @@ def stage1(DOWN=4):
             def tap_read(l, mt, j):
                 m16, q = l & 15, l >> 4
                 src = mt * (16 * 128) + (j % DOWN) * (128 // DOWN) * 128
+                if NEW:
+                    base = (m16 + j // DOWN) * 128 + ((q ^ ((m16 + j // DOWN) & 7)) * 16)
+                    return src + ((base ^ (((5 * (j % DOWN)) & 7) * 16)) ^ (64 if hl else 0))
                 base = (m16 + j // DOWN) * 128 + ((q ^ (((m16 + j // DOWN) >> 1) & 7)) * 16)
                 return src + ((base ^ (((j % DOWN) * (8 // DOWN)) * 16)) ^ (64 if hl else 0))
             extra += report(f"down conv: tap read (inner tiles), {'lo' if hl else 'hi'}", "ds_read_b128", tap_read,
@@ -125,5 +132,9 @@ def stage1(DOWN=4):
 
 
 if __name__ == "__main__":
-    stage1(4)
-    stage1(2)
+    for new in (False, True):
+        NEW = new
+        print(f"===== {'round 3' if new else 'round 2'} layouts")
+        for r in (4, 2):
+            extra = stage1(r)
+            print(f"      extra LDS cycles (above the conflict-free count) summed over the listed variants: {extra}")

@@ -54,7 +54,10 @@ struct RbRow {
     static constexpr int bytes = CH * 4;
     static constexpr int chunks = bytes / 16;
     __device__ static __forceinline__ int swz(int r) {
-        return bytes == 64 ? ((r >> 2) & 3) : (bytes == 128 ? ((r >> 1) & 7) : (r & 15));
+        // 256-byte rows (C = 64): a 4-bit XOR-linear function of r & 7, (r0, r0^r1, r2, r1^r2), found by search with the bank
+        // model of tools/lds_banks.py: conflict-free for 16 consecutive rows starting at ANY row (conv3's taps start at
+        // offsets 0, 1, 2; round 2's r & 15 was 1.33 LDS cycles per ideal one there) and for the 8-lanes-per-row stores
+        return bytes == 64 ? ((r >> 2) & 3) : (bytes == 128 ? ((r >> 1) & 7) : (int)((0x56FC9A30u >> (4 * (r & 7))) & 15u));
     }
     // byte offset of the 8-half chunk holding channels ci .. ci+7 (ci % 8 == 0) of row r; lo = the lo half
     __device__ static __forceinline__ int off(int r, int ci, int lo) {
@@ -82,8 +85,11 @@ struct Rb16Layout {
 
 // weight image: 16-deep k-step ks, part hl, row n: 32 bytes = k 16 ks .. +15 as two 16-byte chunks (k half h),
 // stored at chunk h ^ ((n >> 3) & 1): conflict-free for the 16-lane groups of a ds_read_b128
-__device__ __forceinline__ int rb16_woff(int rows, int ks, int hl, int n, int h) {
-    return ((ks * 2 + hl) * rows + n) * 32 + ((h ^ ((n >> 3) & 1)) * 16);
+// sw: the image is read as v_mfma_f32_32x32x16_f16 operands (lane = (row of 32, k half)); images read as 16x16x32 operands
+// (lane = (row of 16, k quarter)) take no swizzle: there the 16-lane groups of a ds_read_b128 pair rows n and n + 8 with
+// OPPOSITE halves already, and the swizzle would put them on the same banks
+__device__ __forceinline__ int rb16_woff(int rows, int ks, int hl, int n, int h, bool sw = true) {
+    return ((ks * 2 + hl) * rows + n) * 32 + ((h ^ (sw ? ((n >> 3) & 1) : 0)) * 16);
 }
 
 // DBG: timing-experiment build (WT_RB16_DBG); the shipped instantiations test nothing at run time.
@@ -111,6 +117,7 @@ __global__ __launch_bounds__(ROWS / FPW * 64, DOWN ? 2 : 1) void resblock16_kern
     using XR = RbRow<C>;
     using HR = RbRow<L::H>;
     constexpr int NT = ROWS / FPW * 64;              // one wave per FPW frames
+    constexpr bool W3_SW = !(L::H == 16 || FPW == 16), W2_SW = FPW != 16;      // which MFMA shape reads each weight image (rb16_woff)
     extern __shared__ __attribute__((aligned(256))) char smem16[];
     char* xe = smem16 + L::off_xe;
     char* xr = smem16 + L::off_xr;
@@ -123,16 +130,25 @@ __global__ __launch_bounds__(ROWS / FPW * 64, DOWN ? 2 : 1) void resblock16_kern
     float amax = 0.f, wmax = 0.f;        // largest activation / weight magnitude converted to the split-f16 form
     // Byte offset in xr of the 16-byte chunk `chunk` (0 .. C/4 - 1: hi chunks, then lo, per 32 channels) of frame row r.
     // DOWN: frame r = R o + j sits at row j * (ROWS / R) + o ("planes" of equal tap phase) and its chunks are XORed with
-    // ((o >> 1) ^ j * (8 / R)) & 7, so that BOTH 16 consecutive frames (shortcut conv, tile fill, staging) and 16 frames a
-    // stride R apart (one tap of the down conv for 16 output frames) cover all 64 banks.
+    // (o ^ 5 j) & 7: with it the four non-contiguous 16-lane groups of a ds_read_b128 cover all 64 banks BOTH for 32
+    // consecutive frames (shortcut conv) and for 16 frames a stride R apart (one tap of the down conv for 16 output frames);
+    // round 2's ((o >> 1) ^ j * (8 / R)) left the tap reads 1.5-way conflicted (tools/lds_banks.py: the bank model and
+    // the search that picked this form; the 8-byte stores of an MFMA result are 2-way whatever the swizzle).
     auto xr_chunk_off = [&](int r, int chunk) -> int {
         if constexpr (DOWN > 0) {
             const int o = r / DOWN, j = r % DOWN;
-            const int g = ((o >> 1) ^ (j * (8 / DOWN))) & 7;
+            const int g = (o ^ (5 * j)) & 7;
             return (j * (ROWS / DOWN) + o) * XR::bytes + ((chunk ^ g) * 16);
         } else {
             return r * XR::bytes + ((chunk ^ XR::swz(r)) * 16);
         }
+    };
+    // xe (elu(x), read by conv3 with a row offset of 0, 1, 2 per tap): C = 32 stores chunk c of row r at c ^ (r & 7); the
+    // (r >> 1) & 7 of RbRow is conflict-free only for reads that start at an even row (the taps start at odd ones too:
+    // 1.67 LDS cycles per ideal one).  C = 64 keeps RbRow's r & 15.
+    auto xe_off = [&](int r, int ci, int lo) -> int {
+        if constexpr (C == 32) return r * XR::bytes + (((lo * 4 + (ci % 32) / 8) ^ (r & 7)) * 16);
+        else return XR::off(r, ci, lo);
     };
     auto xr_off = [&](int r, int ci, int lo) -> int {              // the 8-half chunk of channels ci .. ci + 7 (cf. RbRow::off)
         constexpr int G = C < 32 ? C : 32;
@@ -148,8 +164,8 @@ __global__ __launch_bounds__(ROWS / FPW * 64, DOWN ? 2 : 1) void resblock16_kern
         for (int i = 0; i < 8; ++i) v[i] = n < L::H ? a.W3[(long)n * L::K1 + k8 + i] : 0.f;
         f16x8 hi, lo;
         rb16_split8(v, hi, lo, wmax);
-        *reinterpret_cast<f16x8*>(w3 + rb16_woff(L::N1, k8 / 16, 0, n, (k8 / 8) & 1)) = hi;
-        *reinterpret_cast<f16x8*>(w3 + rb16_woff(L::N1, k8 / 16, 1, n, (k8 / 8) & 1)) = lo;
+        *reinterpret_cast<f16x8*>(w3 + rb16_woff(L::N1, k8 / 16, 0, n, (k8 / 8) & 1, W3_SW)) = hi;
+        *reinterpret_cast<f16x8*>(w3 + rb16_woff(L::N1, k8 / 16, 1, n, (k8 / 8) & 1, W3_SW)) = lo;
     }
     for (int e = tid; e < C * (L::K2 / 8); e += NT) {
         const int n = e / (L::K2 / 8), k8 = (e - n * (L::K2 / 8)) * 8;
@@ -159,8 +175,8 @@ __global__ __launch_bounds__(ROWS / FPW * 64, DOWN ? 2 : 1) void resblock16_kern
             v[i] = k8 < L::H ? a.W1[(long)n * L::H + k8 + i] : a.Ws[(long)n * C + (k8 - L::H) + i];
         f16x8 hi, lo;
         rb16_split8(v, hi, lo, wmax);
-        *reinterpret_cast<f16x8*>(w2 + rb16_woff(C, k8 / 16, 0, n, (k8 / 8) & 1)) = hi;
-        *reinterpret_cast<f16x8*>(w2 + rb16_woff(C, k8 / 16, 1, n, (k8 / 8) & 1)) = lo;
+        *reinterpret_cast<f16x8*>(w2 + rb16_woff(C, k8 / 16, 0, n, (k8 / 8) & 1, W2_SW)) = hi;
+        *reinterpret_cast<f16x8*>(w2 + rb16_woff(C, k8 / 16, 1, n, (k8 / 8) & 1, W2_SW)) = lo;
     }
     for (int e = tid; e < L::N1 + C; e += NT)
         bb[e] = e < L::N1 ? (e < L::H ? a.b3[e] : 0.f) : (a.b1[e - L::N1] + a.bs[e - L::N1]);
@@ -226,8 +242,8 @@ __global__ __launch_bounds__(ROWS / FPW * 64, DOWN ? 2 : 1) void resblock16_kern
         for (int i = 0; i < 8; ++i) ev[i] = (DBG && (a.dbg & 16)) ? v[i] : rb16_elu(v[i]);
         float unused = 0.f;                  // |elu(v)| <= |v|, which the raw split above has covered (or, for the halo rows, a neighbouring tile's)
         rb16_split8(ev, hi, lo, unused);
-        *reinterpret_cast<f16x8*>(xe + XR::off(r, c8, 0)) = hi;
-        *reinterpret_cast<f16x8*>(xe + XR::off(r, c8, 1)) = lo;
+        *reinterpret_cast<f16x8*>(xe + xe_off(r, c8, 0)) = hi;
+        *reinterpret_cast<f16x8*>(xe + xe_off(r, c8, 1)) = lo;
     };
     if ((long)blockIdx.x < n_tiles) prefetch((int)(blockIdx.x / (unsigned)tiles_per_clip), (int)(blockIdx.x % (unsigned)tiles_per_clip));
     // Folded first conv (seanet.py:117: SConv1d(1 -> 32, k = 7)) as a split-f16 MFMA: x[ch][frame] = sum over k of
@@ -341,8 +357,8 @@ __global__ __launch_bounds__(ROWS / FPW * 64, DOWN ? 2 : 1) void resblock16_kern
                 *reinterpret_cast<f16x4*>(xr + xr_off(xrow, n & ~7, 1) + (n & 7) * 2) = lo;
                 float unused = 0.f;              // |elu(x)| <= |x|
                 rb16_split4(e4, hi, lo, unused);
-                *reinterpret_cast<f16x4*>(xe + XR::off(r, n & ~7, 0) + (n & 7) * 2) = hi;
-                *reinterpret_cast<f16x4*>(xe + XR::off(r, n & ~7, 1) + (n & 7) * 2) = lo;
+                *reinterpret_cast<f16x4*>(xe + xe_off(r, n & ~7, 0) + (n & 7) * 2) = hi;
+                *reinterpret_cast<f16x4*>(xe + xe_off(r, n & ~7, 1) + (n & 7) * 2) = lo;
             }
         } else {
 #pragma unroll
@@ -377,13 +393,13 @@ __global__ __launch_bounds__(ROWS / FPW * 64, DOWN ? 2 : 1) void resblock16_kern
 #pragma unroll
             for (int st = 0; st < 6; ++st) {                        // conv3: K = 3 taps x 64 channels, step = (tap, channel half)
                 const int tap = st >> 1, cb = (st & 1) * 32;
-                const f16x8 bh = *reinterpret_cast<const f16x8*>(xe + XR::off(frame + tap, cb + 8 * q, 0));
-                const f16x8 bl = *reinterpret_cast<const f16x8*>(xe + XR::off(frame + tap, cb + 8 * q, 1));
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(xe + xe_off(frame + tap, cb + 8 * q, 0));
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(xe + xe_off(frame + tap, cb + 8 * q, 1));
                 f16x8 wh[2], wl[2];
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
-                    wh[mt] = *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, 2 * st + (q >> 1), 0, 16 * mt + m16, q & 1));
-                    wl[mt] = *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, 2 * st + (q >> 1), 1, 16 * mt + m16, q & 1));
+                    wh[mt] = *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, 2 * st + (q >> 1), 0, 16 * mt + m16, q & 1, W3_SW));
+                    wl[mt] = *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, 2 * st + (q >> 1), 1, 16 * mt + m16, q & 1, W3_SW));
                 }
                 hm[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[0], bh, hm[0], 0, 0, 0);
                 hc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[0], bh, hc[0], 0, 0, 0);
@@ -423,8 +439,8 @@ __global__ __launch_bounds__(ROWS / FPW * 64, DOWN ? 2 : 1) void resblock16_kern
                 f16x8 wh[4], wl[4];
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
-                    wh[mt] = *reinterpret_cast<const f16x8*>(w2 + rb16_woff(C, 2 * st + (q >> 1), 0, 16 * mt + m16, q & 1));
-                    wl[mt] = *reinterpret_cast<const f16x8*>(w2 + rb16_woff(C, 2 * st + (q >> 1), 1, 16 * mt + m16, q & 1));
+                    wh[mt] = *reinterpret_cast<const f16x8*>(w2 + rb16_woff(C, 2 * st + (q >> 1), 0, 16 * mt + m16, q & 1, W2_SW));
+                    wl[mt] = *reinterpret_cast<const f16x8*>(w2 + rb16_woff(C, 2 * st + (q >> 1), 1, 16 * mt + m16, q & 1, W2_SW));
                 }
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) ym[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[mt], bh, ym[mt], 0, 0, 0);
@@ -475,14 +491,14 @@ __global__ __launch_bounds__(ROWS / FPW * 64, DOWN ? 2 : 1) void resblock16_kern
             if (!(dbg & 2))
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap) {
-                const f16x8 wh = *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, 2 * tap + (q >> 1), 0, m16, q & 1));
-                const f16x8 wl = *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, 2 * tap + (q >> 1), 1, m16, q & 1));
+                const f16x8 wh = *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, 2 * tap + (q >> 1), 0, m16, q & 1, W3_SW));
+                const f16x8 wl = *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, 2 * tap + (q >> 1), 1, m16, q & 1, W3_SW));
                 f16x8 bh[2], bl[2];
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     const int xrow = row0 + 16 * nt + m16 + tap;
-                    bh[nt] = *reinterpret_cast<const f16x8*>(xe + XR::off(xrow, 8 * q, 0));
-                    bl[nt] = *reinterpret_cast<const f16x8*>(xe + XR::off(xrow, 8 * q, 1));
+                    bh[nt] = *reinterpret_cast<const f16x8*>(xe + xe_off(xrow, 8 * q, 0));
+                    bl[nt] = *reinterpret_cast<const f16x8*>(xe + xe_off(xrow, 8 * q, 1));
                 }
                 // issue order: no MFMA directly behind the one it depends on
                 hm[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh[0], hm[0], 0, 0, 0);
@@ -517,12 +533,12 @@ __global__ __launch_bounds__(ROWS / FPW * 64, DOWN ? 2 : 1) void resblock16_kern
             for (int ks = 0; ks < L::K1 / 16; ++ks) {
                 const int tap = (ks * 16) / C, ci = (ks * 16) % C + 8 * fh;
                 const int xrow = row0 + fl + tap;                    // xe row index = frame + 1 + (tap - 1)
-                const f16x8 bh = *reinterpret_cast<const f16x8*>(xe + XR::off(xrow, ci, 0));
-                const f16x8 bl = *reinterpret_cast<const f16x8*>(xe + XR::off(xrow, ci, 1));
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(xe + xe_off(xrow, ci, 0));
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(xe + xe_off(xrow, ci, 1));
     #pragma unroll
                 for (int j = 0; j < TN1; ++j) {
-                    const f16x8 wh = *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, ks, 0, j * 32 + fl, fh));
-                    const f16x8 wl = *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, ks, 1, j * 32 + fl, fh));
+                    const f16x8 wh = *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, ks, 0, j * 32 + fl, fh, W3_SW));
+                    const f16x8 wl = *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, ks, 1, j * 32 + fl, fh, W3_SW));
                     a1m[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, a1m[j], 0, 0, 0);
                     a1c[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, a1c[j], 0, 0, 0);
                     a1c[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, a1c[j], 0, 0, 0);
@@ -571,8 +587,8 @@ __global__ __launch_bounds__(ROWS / FPW * 64, DOWN ? 2 : 1) void resblock16_kern
             }
 #pragma unroll
             for (int j = 0; j < TN2; ++j) {
-                const f16x8 wh = *reinterpret_cast<const f16x8*>(w2 + rb16_woff(C, ks, 0, j * 32 + fl, fh));
-                const f16x8 wl = *reinterpret_cast<const f16x8*>(w2 + rb16_woff(C, ks, 1, j * 32 + fl, fh));
+                const f16x8 wh = *reinterpret_cast<const f16x8*>(w2 + rb16_woff(C, ks, 0, j * 32 + fl, fh, W2_SW));
+                const f16x8 wl = *reinterpret_cast<const f16x8*>(w2 + rb16_woff(C, ks, 1, j * 32 + fl, fh, W2_SW));
                 a2m[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, a2m[j], 0, 0, 0);
                 a2c[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, a2c[j], 0, 0, 0);
                 a2c[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, a2c[j], 0, 0, 0);
@@ -635,9 +651,9 @@ __global__ __launch_bounds__(ROWS / FPW * 64, DOWN ? 2 : 1) void resblock16_kern
 #pragma unroll
                     for (int j = 0; j < DK; ++j) {
                         const char* src = xr + mt * (16 * XR::bytes) + (j % DOWN) * (ROWS / DOWN) * XR::bytes;
-                        const int base = (m16 + j / DOWN) * XR::bytes + ((q ^ (((m16 + j / DOWN) >> 1) & 7)) * 16);
-                        const f16x8 yh = *reinterpret_cast<const f16x8*>(src + (base ^ (((j % DOWN) * (8 / DOWN)) * 16)));
-                        const f16x8 yl = *reinterpret_cast<const f16x8*>(src + (base ^ (((j % DOWN) * (8 / DOWN)) * 16) ^ 64));
+                        const int base = (m16 + j / DOWN) * XR::bytes + ((q ^ ((m16 + j / DOWN) & 7)) * 16);      // o & 7 = (m16 + j / R) & 7
+                        const f16x8 yh = *reinterpret_cast<const f16x8*>(src + (base ^ (((5 * (j % DOWN)) & 7) * 16)));
+                        const f16x8 yl = *reinterpret_cast<const f16x8*>(src + (base ^ (((5 * (j % DOWN)) & 7) * 16) ^ 64));
                         dm = __builtin_amdgcn_mfma_f32_16x16x32_f16(wdh[DOWN ? j : 0], yh, dm, 0, 0, 0);
                         dc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wdl[DOWN ? j : 0], yh, dc, 0, 0, 0);
                         dc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wdh[DOWN ? j : 0], yl, dc2, 0, 0, 0);
