@@ -1031,7 +1031,25 @@ def test_packed_image_round_trip(gpu_model, tmp_path):
     assert torch.equal(m.decode(f1, bandwidth_id=BW), m2.decode(f2, bandwidth_id=BW))
     with pytest.raises(RuntimeError):
         m2.state_dict()
-    parity_log.record(f"packed_load[{name}]", image_mb=img1.nbytes / 1e6, from_packed_s=t_packed, from_state_dict_s=t_state)
+    # the image holds no fp32 copies of the GEMM weights (they are rebuilt from the S32 copies when a plan on the fp32
+    # chain is first created: 22 of 24 significant bits): the fp32 chain of the packed model still meets the usual bar
+    m2.set_gemm_precision("f32")
+    m.set_gemm_precision("f32")
+    try:
+        fa, ca = m.encode_infer(wav, bandwidth_id=BW)
+        fb, cb = m2.encode_infer(wav, bandwidth_id=BW)
+        wa, wb = m.decode(fa, bandwidth_id=BW), m2.decode(fa, bandwidth_id=BW)
+    finally:
+        m.set_gemm_precision("f16x3")
+        m2.set_gemm_precision("f16x3")
+    assert torch.equal(ca, cb)
+    e32 = rel_l2(wb.cpu().numpy(), wa.cpu().numpy())
+    assert e32 < 2e-5, e32
+    m.check_status()
+    m2.check_status()
+    assert img1.nbytes < 650e6, img1.nbytes
+    parity_log.record(f"packed_load[{name}]", image_mb=img1.nbytes / 1e6, from_packed_s=t_packed, from_state_dict_s=t_state,
+                      fp32_chain_packed_vs_exact_rel_l2=e32)
 
 
 # ------------------------------------------------------------------------------------------ round 3

@@ -90,6 +90,8 @@ int main(int argc, char** argv) {
                   {"  r03 with GELU one sub-run at a time", run128x192<EPI_BIAS_GELU, OUT_S32, 524288>},
                   {"  r03 with a vector wave id", run128x192<EPI_BIAS_GELU, OUT_S32, 65536>},
                   {"  r03 + setprio", run128x192<EPI_BIAS_GELU, OUT_S32, 8192>},
+                  {"no epilogue + in-loop fake drain", run128x192<EPI_BIAS_GELU, OUT_S32, 4 + 2097152>},
+                  {"r03 + in-loop fake drain", run128x192<EPI_BIAS_GELU, OUT_S32, 2097152>},
                   {"epilogue without GELU", run128x192<EPI_BIAS_GELU, OUT_S32, 512>},
                   {"epilogue without global stores", run128x192<EPI_BIAS_GELU, OUT_S32, 128>},
                   {"epilogue without GELU and stores", run128x192<EPI_BIAS_GELU, OUT_S32, 512 + 128>},

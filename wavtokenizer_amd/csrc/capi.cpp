@@ -140,6 +140,10 @@ int wt_plan_create(const wt_model* m, int32_t kind, int32_t B, int64_t len, int3
         P->status_dev = static_cast<unsigned*>(dp);
         *P->status_host = 0;
     }
+    // a model that came from a packed image holds no fp32 copies of its GEMM weights until a plan needs them
+    if (m->f32_stale.load() && ((flags & (WT_PLAN_FLAG_FP32_GEMM | WT_PLAN_FLAG_UNFUSED)) || !m->s32_ok ||
+                                (kind == WT_PLAN_SEANET_DECODER && !m->sd_s32_ok)))
+        if (int rc0 = ensure_f32_weights(m)) return rc0;
     plan_begin(P.get());
     int rc;
     if (kind == WT_PLAN_ENCODE) {

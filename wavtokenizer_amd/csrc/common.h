@@ -192,6 +192,7 @@ int launch_gemm(const GemmArgs& a, int pro, int epi, hipStream_t s);
 int launch_gemm16s(const GemmArgs& a, int epi, int out, hipStream_t s);     // out: Out16s
 int gemm16s_vq_parts(int N);
 int launch_split_s32(const float* x, void* out, long n, hipStream_t s, const float* scale_dev = nullptr);
+int launch_unsplit_s32(const void* s32, float* out, long n, float inv_scale, hipStream_t s);     // fp32 = (hi + lo * 2^-11) * inv_scale
 // per-tensor power-of-two scales of two tensors on the device: out3 = {scale_a, scale_b, 1 / (scale_a * scale_b)}
 int launch_pow2_scales(const float* a, long na, const float* b, long nb, unsigned* bits2, float* out3, hipStream_t s);
 

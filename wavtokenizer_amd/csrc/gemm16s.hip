@@ -507,6 +507,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
     // the epilogue's own loads and stores simply queue behind them.  Past the last tile the DMAs are issued all the
     // same with out-of-range offsets (constant wait counts).
     const int nk = p.K / SBK;
+    f32x4 fake = {0.1f * lane, 0.2f, -0.3f, 0.01f * lane};
+    const __amdgpu_buffer_rsrc_t rsFake = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 1024, 0x00020000);
     float amax = 0.f;            // largest magnitude this wave converts to the split-f16 form (range_report at the end)
     // operands may carry a per-tensor power-of-two scale (weights at load, the single-stage entry points): the
     // accumulators are brought back by acc_s, exactly (a power of two), before bias and activation
@@ -583,8 +585,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
                 if (!(dbg & 16)) read_frags(rs, 1, F1);
                 if (!(dbg & 2)) mfma_block(F0);
             }
+            if constexpr ((dbg & 2097152) != 0) {
+                // timing experiment: what an epilogue drained inside the K loop would cost - per K step the GELU + split of one
+                // 4-column run and its two 8-byte stores (out of range: counted, dropped), scheduled among the MFMAs
+                fake = gelu_erfc_s4(fake + (f32x4){1e-3f, 2e-3f, 3e-3f, 4e-3f});
+                f16x4 fh, fl;
+                split4_f16(fake.x, fake.y, fake.z, fake.w, fh, fl);
+                amax = amax4(amax, fake.x, fake.y, fake.z, fake.w);
+                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, fh), rsFake, (int)0x7ffffff0, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, fl), rsFake, (int)0x7ffffff0, 0, 0);
+            }
             if (dbg & 32768) { if (!(dbg & 32)) wait_vm_lgkm<63>(); }                 // timing experiment: DMA issued, never waited for (races)
-            else if (!(dbg & 32)) wait_vm_lgkm<(NSTAGE - 2) * NPT>();
+            else if (!(dbg & 32)) wait_vm_lgkm<(NSTAGE - 2) * NPT + ((dbg & 2097152) ? 2 : 0)>();
             if (!(dbg & 8)) __builtin_amdgcn_s_barrier();
             rs = rs + 1 == NSTAGE ? 0 : rs + 1;
             ws = ws + 1 == NSTAGE ? 0 : ws + 1;
@@ -873,6 +886,21 @@ int launch_split_s32(const float* x, void* out, long n, hipStream_t s, const flo
     if (n % 32) { set_error("split_s32: element count must be a multiple of 32"); return -1; }
     int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
     hipLaunchKernelGGL(split_s32_kernel, dim3(blocks), dim3(256), 0, s, x, static_cast<_Float16*>(out), n, scale_dev, g_launch.status);
+    WT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// S32 -> fp32 (the lazy fp32 GEMM weights of a model that came from a packed image: weights.cpp ensure_f32_weights)
+__global__ __launch_bounds__(256) void unsplit_s32_kernel(const _Float16* __restrict__ in, float* __restrict__ out, long n, float inv_scale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long g = (i >> 5) * 64 + (i & 31);
+        out[i] = ((float)in[g] + (float)in[g + 32] * (1.f / 2048.f)) * inv_scale;
+    }
+}
+int launch_unsplit_s32(const void* s32, float* out, long n, float inv_scale, hipStream_t s) {
+    if (n % 32) { set_error("unsplit_s32: element count must be a multiple of 32"); return -1; }
+    int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(unsplit_s32_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const _Float16*>(s32), out, n, inv_scale);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -98,6 +98,15 @@ struct wt_model {
     bool s32_ok = true;
     bool sd_s32_ok = true;                               // the same for the SEANetDecoder's weights (its plan only)
     float w_amax = 0.f;                                  // largest finite |w| over the GEMM weights
+    // fp32 GEMM weights that the default (S32) plans never read: only plans on the fp32 MFMA chain do (WT_PLAN_FLAG_FP32_GEMM,
+    // the unfused debug twin).  The packed image does not store them (they are 230 of its 720 MB); a model made from one
+    // allocates them and fills them in from the S32 copy when the first such plan is created (w = (hi + lo * 2^-11) /
+    // scale: 22 of fp32's 24 significant bits; a model made from a state dict keeps the exact arrays).  s32 = null:
+    // an array nothing reads after the split (the tap-paired repacking of a down conv)
+    struct LazyF32 { const float* w; const void* s32; int64_t n; float scale; };
+    std::vector<LazyF32> lazy_f32;
+    mutable std::atomic<bool> f32_stale{false};          // the arrays of lazy_f32 hold nothing yet (packed import)
+    mutable std::mutex f32_mu;
     // per-weight power-of-two scale of the S32 copy (tensors whose largest magnitude is far from 1 are stored as
     // w * 2^e; the GEMM brings its accumulators back with acc_scale = 2^-e); absent = 1
     std::map<const float*, float> s32_acc_scale;
@@ -274,6 +283,7 @@ size_t model_export_bytes(const wt_model* M);
 int model_export(const wt_model* M, void* buf, size_t n);
 int model_import(wt_model* M, const void* buf, size_t n);        // M->device set; allocates and uploads
 int packed_info(const void* buf, size_t n, wt_arch* arch, int32_t* version, uint64_t* arch_hash);
+int ensure_f32_weights(const wt_model* M);                        // fills the lazy fp32 arrays of a packed model (first fp32 plan)
 size_t packed_bytes(const void* buf, size_t n);                  // exact length of the image at buf (0: bad header)
 int packed_verify(const void* buf, size_t n);                    // header + bounds + content hash; needs no GPU
 // plan.cpp

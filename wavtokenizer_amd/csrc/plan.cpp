@@ -14,7 +14,12 @@ static bool plan_s32(const wt_plan* P) { return !plan_unfused(P) && !plan_fp32(P
 
 // Everything the S32 chain does not cover (the fp32 plans: WT_PLAN_FLAG_FP32_GEMM, the unfused debug twin, a model whose
 // weights do not fit the split-f16 range) runs on the fp32 MFMA chain of gemm.hip
-static int gemm_auto(const wt_plan*, const GemmArgs& a, int pro, int epi, hipStream_t s) { return launch_gemm(a, pro, epi, s); }
+static int gemm_auto(const wt_plan* P, const GemmArgs& a, int pro, int epi, hipStream_t s) {
+    // safety net for a model that came from a packed image (its fp32 GEMM weights are rebuilt on demand: wt_plan_create does
+    // it for the plans it can tell will need them; any other fp32 GEMM finds them here, in the plan's first, eager call)
+    if (P->model->f32_stale.load()) if (int rc = ensure_f32_weights(P->model)) return rc;
+    return launch_gemm(a, pro, epi, s);
+}
 
 // Both operands pre-split (S32): the activations were written in S32 by their producer, the weight has an S32 copy
 static int gemm_s32(const wt_plan* P, const GemmArgs& a, int epi, int out, hipStream_t s) {

@@ -417,7 +417,7 @@ int build_model(wt_model* M, TensorMap& tm) {
 // lies outside [2^-6, 2^12] is stored as w * 2^e (maximum brought into [1, 2)) and its GEMMs multiply their
 // accumulators by 2^-e (GemmArgs::acc_scale; powers of two: exact).  A non-finite weight cannot be split at all:
 // the model then runs on the fp32 MFMA chain (wt_model::s32_ok).
-static int add_s32(wt_model* M, const float* w, long n, bool* split_ok = nullptr) {
+static int add_s32(wt_model* M, const float* w, long n, bool* split_ok = nullptr, bool gemm_only = false) {
     if (!w || n <= 0 || (n % 32)) return 0;
     if (!split_ok) split_ok = &M->s32_ok;
     std::vector<float> h((size_t)n);
@@ -449,16 +449,18 @@ static int add_s32(wt_model* M, const float* w, long n, bool* split_ok = nullptr
     M->weight_bytes += n * 4;
     if (int rc = launch_split_s32(w, d, n, nullptr, scale_dev)) return rc;
     M->s32[w] = d;
+    // gemm_only: nothing but a GEMM reads this fp32 array, and the default plans multiply by the S32 copy (wt_model::lazy_f32)
+    if (gemm_only && finite) M->lazy_f32.push_back({w, d, (int64_t)n, scale});
     return 0;
 }
 
 int build_splits(wt_model* M) {
     const wt_arch& a = M->arch;
     const int D = a.dim, I = a.intermediate_dim;
-    auto conv32 = [&](const ConvW& c) { return (c.cin % 32) ? 0 : add_s32(M, c.w, (long)c.cout * c.k * c.cin); };
+    auto conv32 = [&](const ConvW& c, bool gemm_only = true) { return (c.cin % 32) ? 0 : add_s32(M, c.w, (long)c.cout * c.k * c.cin, nullptr, gemm_only); };
     // the SEANetDecoder's weights are all zeros -> NaN after the weight-norm fold when a checkpoint without them was
     // loaded into the full module tree: they only decide how the SEANetDecoder plan runs
-    auto conv32sd = [&](const ConvW& c) { return (c.cin % 32) ? 0 : add_s32(M, c.w, (long)c.cout * c.k * c.cin, &M->sd_s32_ok); };
+    auto conv32sd = [&](const ConvW& c) { return (c.cin % 32) ? 0 : add_s32(M, c.w, (long)c.cout * c.k * c.cin, &M->sd_s32_ok, true); };
     for (const ResStage& st : M->stages) {      // encoder chain on S32 operands (build_encode)
         if (st.down.cin % 32 == 0 && st.down.k == 2 * st.r && st.down.k <= 32) {
             // k = 2 * stride: every input frame feeds two output frames (taps j and j + stride).  Packing the taps as
@@ -475,38 +477,41 @@ int build_splits(wt_model* M) {
             float* dpk = nullptr;
             if (int rc = upload(M, pk, &dpk)) return rc;
             if (int rc = add_s32(M, dpk, n)) return rc;
+            M->lazy_f32.push_back({dpk, nullptr, (int64_t)n, 1.f});      // only the split above ever read the repacked copy
             M->s32[st.down.w] = M->s32.at(dpk);
             if (M->s32_acc_scale.count(dpk)) M->s32_acc_scale[st.down.w] = M->s32_acc_scale.at(dpk);
             M->s32_tap_pair[st.down.w] = true;
         } else
-        if (int rc = conv32(st.down)) return rc;
-        if (int rc = conv32(st.c3)) return rc;
-        if (int rc = conv32(st.c1)) return rc;
-        if (int rc = conv32(st.sc)) return rc;
+        if (int rc = conv32(st.down, false)) return rc;
+        // the fused resblock kernels (C = 32, 64) read their conv weights in fp32 and split them themselves
+        const bool fused = resblock_fusable(st.C);
+        if (int rc = conv32(st.c3, !fused)) return rc;
+        if (int rc = conv32(st.c1, !fused)) return rc;
+        if (int rc = conv32(st.sc, !fused)) return rc;
         if (st.cat.w) if (int rc = conv32(st.cat)) return rc;
     }
-    if (int rc = add_s32(M, M->enc_lstm.Wih0, 4L * M->H * M->H)) return rc;
+    if (int rc = add_s32(M, M->enc_lstm.Wih0, 4L * M->H * M->H, nullptr, true)) return rc;
     if (int rc = conv32(M->enc_final)) return rc;
-    if (int rc = add_s32(M, M->embed, (long)a.vq_bins * 512)) return rc;
+    if (int rc = add_s32(M, M->embed, (long)a.vq_bins * 512)) return rc;        // (the gathers read the fp32 codebook)
     if (int rc = conv32(M->bb_embed)) return rc;
     for (int i = 0; i < 4; ++i) {
         if (int rc = conv32(M->res[i].c1)) return rc;
         if (int rc = conv32(M->res[i].c2)) return rc;
     }
     for (const CnxBlock& c : M->cnx) {
-        if (int rc = add_s32(M, c.W1, (long)I * D)) return rc;
-        if (int rc = add_s32(M, c.W2, (long)D * I)) return rc;
+        if (int rc = add_s32(M, c.W1, (long)I * D, nullptr, true)) return rc;
+        if (int rc = add_s32(M, c.W2, (long)D * I, nullptr, true)) return rc;
     }
-    if (int rc = add_s32(M, M->head_W, 2L * M->Kb * D)) return rc;
-    if (int rc = add_s32(M, M->istft_W, 4L * M->Kq * M->Kq)) return rc;
-    if (int rc = add_s32(M, M->at_Wqk, 2L * D * D)) return rc;
-    if (int rc = add_s32(M, M->at_Wv, (long)D * D)) return rc;
-    if (int rc = add_s32(M, M->at_Wp, (long)D * D)) return rc;
+    if (int rc = add_s32(M, M->head_W, 2L * M->Kb * D, nullptr, true)) return rc;
+    if (int rc = add_s32(M, M->istft_W, 4L * M->Kq * M->Kq, nullptr, true)) return rc;
+    if (int rc = add_s32(M, M->at_Wqk, 2L * D * D, nullptr, true)) return rc;
+    if (int rc = add_s32(M, M->at_Wv, (long)D * D, nullptr, true)) return rc;
+    if (int rc = add_s32(M, M->at_Wp, (long)D * D, nullptr, true)) return rc;
     if (M->has_seadec) {
         if (int rc = conv32sd(M->sd_first)) return rc;
-        if (int rc = add_s32(M, M->sd_lstm.Wih0, 4L * M->H * M->H, &M->sd_s32_ok)) return rc;
+        if (int rc = add_s32(M, M->sd_lstm.Wih0, 4L * M->H * M->H, &M->sd_s32_ok, true)) return rc;
         for (const SeaDecStage& st : M->sd_stages) {
-            if (st.tr_wp && st.cin % 16 == 0) if (int rc = add_s32(M, st.tr_wp, (long)st.r * st.cout * 2 * st.cin, &M->sd_s32_ok)) return rc;
+            if (st.tr_wp && st.cin % 16 == 0) if (int rc = add_s32(M, st.tr_wp, (long)st.r * st.cout * 2 * st.cin, &M->sd_s32_ok, true)) return rc;
             if (resblock_fusable(st.cout)) continue;            // its convs run inside resblock16
             if (int rc = conv32sd(st.sc)) return rc;
             if (int rc = conv32sd(st.c3)) return rc;
@@ -526,7 +531,7 @@ int build_splits(wt_model* M) {
 // header (magic, version, the wt_arch and a hash of it) and the model struct with every pointer written as
 // (allocation index).  Loading it is allocate + upload + fix up pointers: nothing is folded, packed or split again.
 static constexpr uint32_t PACK_MAGIC = 0x4b505457u;     // "WTPK"
-static constexpr int32_t PACK_VERSION = 4;
+static constexpr int32_t PACK_VERSION = 5;
 
 static uint64_t arch_hash_of(const wt_arch& a) {        // FNV-1a over the architecture struct and the layout version
     uint64_t h = 1469598103934665603ull;
@@ -616,6 +621,8 @@ static void archive_model(Archive& ar, wt_model* M) {
         }
     };
     map_ptr(M->s32, [&](void*& v) { ar.ptr(v); });
+    n = ar.count(M->lazy_f32.size(), 1 << 12); M->lazy_f32.resize(n);
+    for (wt_model::LazyF32& z : M->lazy_f32) { ar.ptr(z.w); ar.ptr(z.s32); ar.pod(z.n); ar.pod(z.scale); }
     map_ptr(M->s32_tap_pair, [&](bool& v) { ar.pod(v); });
     map_ptr(M->s32_acc_scale, [&](float& v) { ar.pod(v); });
 }
@@ -645,9 +652,21 @@ static uint64_t body_hash_of(const char* p, size_t n) {
     return (h[0] ^ (h[1] * 3) ^ (h[2] * 5) ^ (h[3] * 7)) * K;
 }
 
+// allocation table entry of an array the image does not store (wt_model::lazy_f32): its size with this bit set
+static constexpr uint64_t PACK_NOT_STORED = 1ull << 63;
+
+static std::vector<bool> lazy_allocs(const wt_model* M) {
+    std::vector<bool> lazy(M->allocs.size(), false);
+    for (const wt_model::LazyF32& z : M->lazy_f32)
+        for (size_t i = 0; i < M->allocs.size(); ++i)
+            if (M->allocs[i] == static_cast<const void*>(z.w)) lazy[i] = true;       // lazy arrays are whole allocations
+    return lazy;
+}
+
 size_t model_export_bytes(const wt_model* M) {
-    size_t total = sizeof(PackHeader) + M->allocs.size() * sizeof(uint64_t) + (1u << 16);      // struct section: generous bound
-    for (size_t b : M->alloc_bytes) total += (b + 255) / 256 * 256;
+    size_t total = sizeof(PackHeader) + M->allocs.size() * sizeof(uint64_t) + (1u << 17);      // struct section: generous bound
+    const std::vector<bool> lazy = lazy_allocs(M);
+    for (size_t i = 0; i < M->allocs.size(); ++i) if (!lazy[i]) total += (M->alloc_bytes[i] + 255) / 256 * 256;
     return total + 256;
 }
 
@@ -663,19 +682,22 @@ int model_export(const wt_model* Mc, void* buf, size_t n) {
     PackHeader h{};
     h.magic = PACK_MAGIC; h.version = PACK_VERSION; h.arch = M->arch; h.arch_hash = arch_hash_of(M->arch);
     h.n_allocs = M->allocs.size(); h.struct_bytes = st.size();
+    if (M->f32_stale.load()) if (int rc = ensure_f32_weights(M)) return rc;       // (nothing lazy is exported, but keep the model whole)
+    const std::vector<bool> lazy = lazy_allocs(M);
     size_t pos = sizeof(PackHeader) + M->allocs.size() * sizeof(uint64_t) + st.size();
     pos = (pos + 255) / 256 * 256;
     const size_t payload0 = pos;
-    for (size_t b : M->alloc_bytes) pos += (b + 255) / 256 * 256;
+    for (size_t i = 0; i < M->allocs.size(); ++i) if (!lazy[i]) pos += (M->alloc_bytes[i] + 255) / 256 * 256;
     h.payload_bytes = pos - payload0;
     if (pos > n) { set_error("wt_model_export: buffer too small (wt_model_export_bytes)"); return WT_ERR_INVALID; }
     char* o = static_cast<char*>(buf);
     std::memset(o, 0, payload0);
-    for (size_t i = 0; i < M->allocs.size(); ++i) { uint64_t b = M->alloc_bytes[i]; std::memcpy(o + sizeof(h) + i * 8, &b, 8); }
+    for (size_t i = 0; i < M->allocs.size(); ++i) { uint64_t b = M->alloc_bytes[i] | (lazy[i] ? PACK_NOT_STORED : 0); std::memcpy(o + sizeof(h) + i * 8, &b, 8); }
     std::memcpy(o + sizeof(h) + M->allocs.size() * 8, st.data(), st.size());
     pos = payload0;
     WT_HIP_CHECK(hipDeviceSynchronize());
     for (size_t i = 0; i < M->allocs.size(); ++i) {
+        if (lazy[i]) continue;
         const size_t b = M->alloc_bytes[i], padded = (b + 255) / 256 * 256;
         WT_HIP_CHECK(hipMemcpy(o + pos, M->allocs[i], b, hipMemcpyDeviceToHost));
         std::memset(o + pos + b, 0, padded - b);
@@ -725,6 +747,10 @@ int packed_verify(const void* buf, size_t n) {
     for (size_t i = 0; i < h.n_allocs; ++i) {
         uint64_t b;
         std::memcpy(&b, in + sizeof(h) + i * 8, 8);
+        if (b & PACK_NOT_STORED) {               // allocated on import, filled in later (wt_model::lazy_f32): bounded, no payload
+            if ((b & ~PACK_NOT_STORED) == 0 || (b & ~PACK_NOT_STORED) > (1ull << 32)) { set_error("packed image: bad size of an unstored array"); return WT_ERR_INVALID; }
+            continue;
+        }
         if (b == 0 || b > n - pos || (b + 255) / 256 * 256 > n - pos) { set_error("packed image: allocation table does not fit the payload"); return WT_ERR_INVALID; }
         pos += (b + 255) / 256 * 256;
     }
@@ -743,19 +769,52 @@ int model_import(wt_model* M, const void* buf, size_t n) {
     for (size_t i = 0; i < h.n_allocs; ++i) {
         uint64_t b;
         std::memcpy(&b, in + sizeof(h) + i * 8, 8);
+        const bool stored = !(b & PACK_NOT_STORED);
+        b &= ~PACK_NOT_STORED;
         const size_t padded = (b + 255) / 256 * 256;
-        if (pos + padded > n) { set_error("packed image: truncated payload"); return WT_ERR_INVALID; }
+        if (stored && pos + padded > n) { set_error("packed image: truncated payload"); return WT_ERR_INVALID; }
         void* d = nullptr;
         WT_HIP_CHECK(hipMalloc(&d, b));
         M->allocs.push_back(d);
         M->alloc_bytes.push_back(b);
-        WT_HIP_CHECK(hipMemcpy(d, in + pos, b, hipMemcpyHostToDevice));
-        pos += padded;
+        if (stored) {
+            WT_HIP_CHECK(hipMemcpy(d, in + pos, b, hipMemcpyHostToDevice));
+            pos += padded;
+        } else {
+            M->f32_stale.store(true);
+        }
     }
     Archive ar;
     ar.saving = false; ar.in = in + sizeof(h) + h.n_allocs * 8; ar.n = h.struct_bytes; ar.allocs = &M->allocs; ar.alloc_bytes = &M->alloc_bytes;
     archive_model(ar, M);
     if (!ar.ok || ar.pos != ar.n) { set_error("packed image: model section does not match this library's layout"); return WT_ERR_INVALID; }
+    // every lazy entry must name whole arrays of plausible size (the file is not trusted)
+    for (const wt_model::LazyF32& z : M->lazy_f32) {
+        size_t iw = M->allocs.size(), is = M->allocs.size();
+        for (size_t i = 0; i < M->allocs.size(); ++i) {
+            if (M->allocs[i] == static_cast<const void*>(z.w)) iw = i;
+            if (z.s32 && M->allocs[i] == z.s32) is = i;
+        }
+        if (iw == M->allocs.size() || z.n <= 0 || (z.n % 32) || (size_t)z.n * 4 > M->alloc_bytes[iw] ||
+            (z.s32 && (is == M->allocs.size() || (size_t)z.n * 4 > M->alloc_bytes[is])) || !(z.scale > 0.f) || !std::isfinite(z.scale)) {
+            set_error("packed image: bad entry in the list of unstored fp32 arrays"); return WT_ERR_INVALID;
+        }
+    }
+    return WT_OK;
+}
+
+// The fp32 GEMM weights a packed image does not store, rebuilt from their S32 copies: w = (hi + lo * 2^-11) / scale.  Called
+// when the first plan on the fp32 chain is created for a model that came from a packed image (and before such a model is
+// exported again).  22 of fp32's 24 significant bits survive; a model made from a state dict keeps the exact arrays.
+int ensure_f32_weights(const wt_model* M) {
+    std::lock_guard<std::mutex> lock(M->f32_mu);
+    if (!M->f32_stale.load()) return WT_OK;
+    for (const wt_model::LazyF32& z : M->lazy_f32) {
+        if (!z.s32) continue;                      // nothing reads it
+        if (int rc = launch_unsplit_s32(z.s32, const_cast<float*>(z.w), (long)z.n, 1.f / z.scale, nullptr)) return rc;
+    }
+    WT_HIP_CHECK(hipDeviceSynchronize());
+    M->f32_stale.store(false);
     return WT_OK;
 }
 
