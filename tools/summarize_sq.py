@@ -2,7 +2,7 @@
 """SQ counters per launch from the passes of tools/pmc_kernel.sh (rocprofv3 --pmc, 4 counters per pass,
 --kernel-trace only): mean over the launches of each kernel, summed over the device.
 
-    python tools/summarize_sq.py gpurun_out profiles/rNN_sq_counters.md
+    python tools/summarize_sq.py gpurun_out profiles/rNN_sq_counters.md [tag]      (tag of tools/pmc_kernel.sh, default pmck)
 """
 import collections
 import csv
@@ -12,10 +12,10 @@ import re
 import sys
 
 
-def main(root, out_md):
+def main(root, out_md, tag="pmck"):
     vals = collections.defaultdict(lambda: collections.defaultdict(list))     # kernel -> counter -> values
     meta = {}
-    for d in sorted(glob.glob(os.path.join(root, "pmck_*"))):
+    for d in sorted(glob.glob(os.path.join(root, tag + "_*"))):
         files = sorted(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
         if not files:
             continue
@@ -46,4 +46,4 @@ def main(root, out_md):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])
