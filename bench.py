@@ -155,6 +155,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--lanes", type=int, default=1, help="N = 1 only: steps in flight on separate HIP streams (StepRunner(lanes=...)); "
+                    "the default line times one step after the other and reports the two-lane rate in other_configs")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured path); gloo only rehearses the N>1 flow on a box with "
                          "fewer GPUs than ranks (ranks share GPUs, collectives go through host memory)")
@@ -235,10 +237,10 @@ def main():
     wav = torch.from_numpy(clips_np).to(dev)
     bw = torch.tensor([0])
     L = arch.frames(T)
-    runner = Runner(model, wav, bw, dist, world, rank, not args.no_gather, args.backend)
+    runner = Runner(model, wav, bw, dist, world, rank, not args.no_gather, args.backend, lanes=args.lanes if world == 1 else 1)
     runner.step()                                                  # creates the plans
     runner.drain()
-    dplan = model._engine.plans[(_capi.WT_PLAN_DECODE, B, L, model._graph_flags(B))][0]
+    dplan = next(p for k, (p, _w) in model._engine.plans.items() if k[:4] == (_capi.WT_PLAN_DECODE, B, L, model._graph_flags(B)))
     blocks, kern = run_blocks(runner, args.steps, max(0, args.warmup - 1), args.repeats, (dplan, b"cnx.pwconv1"))
     model.check_status()
     own_blocks = list(runner.own_blocks)
@@ -251,7 +253,8 @@ def main():
                 "ms_per_step_own_clock": [round(1e3 * t / args.steps, 3) for t in own_blocks],
                 "exchange_wait_ms_per_step": round(1e3 * runner.wait_s / max(1, runner.exchanges), 3),
                 "exchanges": runner.exchanges,
-                "persistent_lstm": bool(getattr(model, "_plan_flags", 0) & _capi.WT_PLAN_FLAG_STEP_LSTM) is False}
+                # (a lost co-residency would have raised in check_status() above)
+                "persistent_lstm": not (getattr(model, "_plan_flags", 0) & _capi.WT_PLAN_FLAG_STEP_LSTM)}
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
         ranks_info = gathered
@@ -300,7 +303,7 @@ def main():
                        **({"p50_encode_infer_ms_rank0": round(p50_encode_ms, 3)} if p50_encode_ms is not None else {}),
                        "weights": "random-init (synth seed 0)", "model_load_s": round(load_s, 2),
                        "hbm_weight_bytes": int(_capi.lib.wt_model_weight_bytes(model._engine.model)),
-                       "parallelism": f"clips sharded dp{world}",
+                       "parallelism": f"clips sharded dp{world}", "lanes": runner.lanes,
                        **({"ranks": ranks_info} if ranks_info is not None else {}),
                        "gather": ("codes all_gather + waveform gather to rank 0 (%s), asynchronous: step i's exchange runs beside step i+1's decode "
                                   "(never beside the persistent LSTM), all finished inside the timed region" % ("RCCL" if args.backend == "nccl" else "gloo rehearsal"))
@@ -389,6 +392,22 @@ def main():
             "end_to_end_frac_of_fp32_mfma_peak_157.3": round(gflop_per_clip(args.arch, arch, clip_s) * B * 1e9 / (ms32 * 1e-3) / 1e12 / 157.3, 4),
             "steps": 5, "blocks": 3}
         del r32
+
+        # the headline workload with two steps in flight: step i+1's encode_infer on a second HIP stream beside step i's decode
+        # (StepRunner(lanes=2): one plan + workspace per stream, the persistent LSTM launches of the two streams chained by the
+        # library).  Same kernels and results; the second stream fills launch gaps and the partly idle last round of each GEMM
+        r2 = Runner(model, wav, bw, None, 1, 0, False, args.backend, lanes=2)
+        r2.step(); r2.step(); r2.drain()
+        blk, _ = run_blocks(r2, args.steps, 2, 3)
+        ms2 = statistics.median(1e3 * t / args.steps for t in blk)
+        model.check_status()
+        other["two_lane_pipeline_64x3s"] = {
+            "what": "configs[1], steps issued alternately on two HIP streams (sharding.StepRunner(lanes=2)); not the headline: "
+                    "the headline times one step after the other on one stream",
+            "ms_per_step": round(ms2, 3), "audio_s_per_s": round(B * clip_s / (ms2 * 1e-3), 1),
+            "vs_one_stream": round(line["ms_per_step"] / ms2, 4), "steps": args.steps, "blocks": 3}
+        del r2
+        model._engine.drop(lambda k: len(k) == 5)
 
         # BASELINE configs[4], per-GPU share: hop-600, 32 clips x 30 s
         wav30 = torch.from_numpy(synth.make_clips(32, 30 * SAMPLE_RATE, seed=1000 * 4)).to(dev)

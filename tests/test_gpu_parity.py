@@ -1283,3 +1283,27 @@ def test_batch_beyond_the_persistent_lstm_limit(gpu_model):
     fb, cb = m.encode_infer(wav[65:].contiguous(), bandwidth_id=BW)
     assert torch.equal(c, torch.cat([ca, cb], dim=1)) and torch.equal(f, torch.cat([fa, fb], dim=0))
     m.check_status()
+
+
+def test_two_lanes_match_one_stream(gpu_model):
+    """One model called from two HIP streams at once (sharding.StepRunner(lanes=2): step i+1's encode_infer beside step i's
+    decode).  Every stream gets its own plan and workspace (pretrained._Engine._key) and the library chains the persistent
+    LSTM launches across streams (capi.cpp LstmChain), so the results are those of the single-stream calls, bit for bit, for
+    the whole-batch form (B = 20, persistent LSTM) and for the graph-replay form (B = 2)."""
+    from wavtokenizer_amd import synth
+    from wavtokenizer_amd.sharding import StepRunner
+    name, m, _sd = gpu_model
+    for B, T in ((20, 9600), (2, 7200)):
+        wav = torch.from_numpy(synth.make_clips(B, T, seed=4200 + B)).cuda()
+        f0, c0 = m.encode_infer(wav, bandwidth_id=BW)
+        w0 = m.decode(f0, bandwidth_id=BW)
+        torch.cuda.synchronize()
+        runner = StepRunner(m, wav, BW, None, 1, 0, gather=False, lanes=2)
+        outs = [runner.step() for _ in range(6)]
+        runner.drain()
+        torch.cuda.synchronize()
+        for codes, out, _ in outs:
+            assert torch.equal(codes, c0) and torch.equal(out, w0)
+        keys = [k for k in m._engine.plans if len(k) == 5 and k[1] == B]
+        assert len({k[4] for k in keys}) == 2, keys                  # one plan set per lane stream
+        m.check_status()

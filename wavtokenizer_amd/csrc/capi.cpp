@@ -233,6 +233,39 @@ static unsigned consume_status(const wt_plan* p, unsigned* own = nullptr) {
     return mb;
 }
 
+// Two persistent LSTM launches must never share the GPU: lstm_persist_kernel spins until all of its workgroups are resident
+// (one per CU), so two of them enqueued on different streams could each hold part of the CUs and wait for the rest until
+// their spin bounds expire (both calls then fail with WT_ERR_LSTM_SYNC).  Calls that carry one are therefore chained per
+// device: a call on another stream than the previous one first waits (on the GPU, hipStreamWaitEvent) for the event recorded
+// behind that previous call.  The lock is held from the wait to the record, so concurrent host threads are ordered too.
+// Kernels of other plans may run beside a persistent launch: they finish on their own and its workgroups then take their CUs.
+struct LstmChain {
+    std::mutex mu;
+    hipEvent_t ev = nullptr;
+    hipStream_t last = nullptr;
+    bool have = false;
+};
+static LstmChain g_lstm_chain[64];
+struct LstmChainScope {
+    LstmChain* ch = nullptr;
+    hipStream_t stream = nullptr;
+    int rc = WT_OK;
+    LstmChainScope(const wt_plan* p, hipStream_t s) {
+        if (!p->uses_persist || p->model->device < 0 || p->model->device >= 64) return;
+        ch = &g_lstm_chain[p->model->device];
+        stream = s;
+        ch->mu.lock();
+        if (ch->have && ch->last != s && hipStreamWaitEvent(s, ch->ev, 0) != hipSuccess) { set_error("hipStreamWaitEvent failed"); rc = WT_ERR_HIP; }
+    }
+    ~LstmChainScope() {
+        if (!ch) return;
+        if (!ch->ev && hipEventCreateWithFlags(&ch->ev, hipEventDisableTiming) != hipSuccess) ch->ev = nullptr;
+        ch->have = ch->ev && hipEventRecord(ch->ev, stream) == hipSuccess;
+        ch->last = stream;
+        ch->mu.unlock();
+    }
+};
+
 static int run_plan_locked(const wt_plan* p, const RunCtx& c);
 static int run_plan(const wt_plan* p, const RunCtx& c) {
     std::lock_guard<std::mutex> lock(p->mu);
@@ -252,6 +285,8 @@ static int run_plan(const wt_plan* p, const RunCtx& c) {
         explicit CtxScope(unsigned* s) { g_launch.status = s; }
         ~CtxScope() { g_launch.status = nullptr; }
     } scope(reinterpret_cast<unsigned*>(c.ws + p->bufs[p->ctl].off));
+    LstmChainScope chain(p, c.stream);
+    if (chain.rc) return chain.rc;
     return run_plan_locked(p, c);
 }
 

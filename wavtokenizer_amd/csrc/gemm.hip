@@ -259,25 +259,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 
     float* __restrict__ Cg = p.C + (long)z * p.zC;
     if constexpr (EPI == EPI_HEAD) {
-        static_assert(TN % 2 == 0, "head epilogue pairs column tiles");
+        // packed rows: 32-row groups = 16 log-magnitude rows, then the 16 phase rows of the same slots (weights.cpp).  A lane
+        // holds one column of the 32-column tile, so the phase of lane l < 16 sits in lane l + 16 (same register)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j + 1 < TN; j += 2) {
-                const int pc = n_w + j * 32 + col_l;        // packed column of the log-magnitude
-                if (pc < p.N) {   // N % 64 == 0, so the paired phase column pc+32 is in range too
-                    const float bmag = p.bias[pc], bph = p.bias[pc + 32];
-                    const int f = (pc >> 6) * 32 + col_l;   // frequency bin
+            for (int j = 0; j < TN; ++j) {
+                const int pc = n_w + j * 32 + col_l;        // packed column
+                const bool is_mag = (col_l & 16) == 0;
+                const bool in = pc < p.N;                   // N % 32 == 0: the partner column is in range with it
+                const float bme = in ? p.bias[pc] : 0.f;
+                const int f = (pc >> 5) * 16 + (col_l & 15);   // spectrum slot
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = m_w + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
-                        if (m < p.M) {
-                            float mag = expf(acc[i][j][r] + bmag);          // heads.py:55
-                            mag = fminf(mag, 100.f);                         // heads.py:56 clip(max=1e2)
-                            const float ph = acc[i][j + 1][r] + bph;
-                            Cg[(long)m * p.c_rstride + f] = mag * cosf(ph);  // heads.py:58,65
-                            Cg[(long)m * p.c_rstride + p.head_kb + f] = mag * sinf(ph);
-                        }
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m_w + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+                    const float mine = acc[i][j][r] + bme;
+                    const float ph = __shfl_xor(mine, 16, 64);
+                    if (is_mag && in && m < p.M) {
+                        float mag = expf(mine);                         // heads.py:55
+                        mag = fminf(mag, 100.f);                         // heads.py:56 clip(max=1e2)
+                        Cg[(long)m * p.c_rstride + f] = mag * cosf(ph);  // heads.py:58,65
+                        Cg[(long)m * p.c_rstride + p.head_kb + f] = mag * sinf(ph);
                     }
                 }
             }

@@ -154,6 +154,37 @@ __device__ __forceinline__ void gelu_erfc_x16(f32x4 (&v)[4]) {
     }
 }
 
+// sin and cos of one argument for the ISTFT head (heads.py:58-59): three-constant Cody-Waite reduction by pi/2 (exact for the
+// |x| < 2^15 it is used for: the first constant has 8 significant bits, every step is one fma) and the classic degree-7 / 8
+// minimax polynomials on [-pi/4, pi/4] (about 1 ulp).  libm's sincosf carries a Payne-Hanek path for huge arguments that
+// hipcc evaluates branch-free for every lane: 128 64-bit multiply-adds and 450 selects per 16 values in the r02 epilogue.
+// Phases beyond 2^15 (never seen; a Linear output) take libm's path.
+__device__ __forceinline__ void sincos_head(float x, float& s, float& c) {
+    if (__builtin_expect(!(fabsf(x) < 32768.f), 0)) { sincosf(x, &s, &c); return; }
+    const float k = rintf(x * 0.63661977236758134308f);
+    float r = fmaf(-k, 1.5703125f, x);
+    r = fmaf(-k, 4.837512969970703125e-4f, r);
+    r = fmaf(-k, 7.54978995489188216e-8f, r);
+    const float z = r * r;
+    float sp = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    sp = fmaf(sp, z, -1.6666654611e-1f);
+    const float sr = fmaf(sp * z, r, r);
+    float cp = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    cp = fmaf(cp, z, 4.166664568298827e-2f);
+    const float cr = fmaf(cp * z, z, fmaf(z, -0.5f, 1.f));
+    const int q = (int)k;
+    const float s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+    s = (q & 2) ? -s0 : s0;
+    c = ((q + 1) & 2) ? -c0 : c0;
+}
+// e^x to about 2 ulp: x = n ln2 + r with a two-constant ln2, 2^n by ldexp (heads.py:55)
+__device__ __forceinline__ float exp_head(float x) {
+    const float n = rintf(x * 1.44269504088896340736f);
+    float r = fmaf(-n, 0.693145751953125f, x);
+    r = fmaf(-n, 1.42860682030941723212e-6f, r);
+    return ldexpf(__builtin_amdgcn_exp2f(r * 1.44269504088896340736f), (int)n);
+}
+
 // fp32 value -> S32 slots of element n (n & 31 = slot) in the group that starts at `grp` (a _Float16*)
 __device__ __forceinline__ void store_s32(_Float16* grp, int slot, float v) {
     const _Float16 h = (_Float16)v;
@@ -255,7 +286,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
 
     // bias / gamma cache (see the persistent loop): the vectors of the epilogues that store between their loads
     constexpr bool PCACHE = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ELU || EPI == EPI_BIAS_RES ||
-                            EPI == EPI_BIAS_RES_ELU || EPI == EPI_BIAS_GAMMA_RES;
+                            EPI == EPI_BIAS_RES_ELU || EPI == EPI_BIAS_GAMMA_RES || EPI == EPI_HEAD;
     constexpr int PC_BYTES = WN * 4 * (EPI == EPI_BIAS_GAMMA_RES ? 2 : 1);
     const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.bias ? p.bias : p.C), 0, p.bias ? p.N * 4 : 0, 0x00020000);
@@ -697,31 +728,84 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
                 }
             }
     } else if constexpr (EPI == EPI_HEAD) {
-        static_assert(TN % 2 == 0, "head epilogue pairs column tiles");
+        // packed rows come in 32-row groups: 16 log-magnitude rows, then the 16 phase rows of the same spectrum slots
+        // (weights.cpp), so every 32 x 32 block holds both halves of 16 slots whatever the tile width: the sub-run s of
+        // columns < 16 pairs with the sub-run of the same rows 16 columns on
+        auto head_run = [&](int i, int j, int h, f32x4& re, f32x4& im) {
+            const int s = MF ? 2 * h : h, sp = MF ? s + 1 : s + 2;
+            const int pc = n_w + j * 32 + sub_col(s);         // packed row of the log-magnitude; phase 16 later
+            const f32x4 bmag = *reinterpret_cast<const f32x4*>(pcw + (pc - n_w) * 4);
+            const f32x4 bph = *reinterpret_cast<const f32x4*>(pcw + (pc + 16 - n_w) * 4);
+            const f32x4 lm = acc4(i, j, s) + bmag, ph = acc4(i, j, sp) + bph;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float mag = fminf((dbg & 4194304) ? expf(lm[e]) : exp_head(fminf(lm[e], 88.f)), 100.f);      // heads.py:55-56
+                float sn, cs;
+                if (dbg & 4194304) sincosf(ph[e], &sn, &cs); else sincos_head(ph[e], sn, cs);     // one range reduction for both
+                re[e] = mag * cs;
+                im[e] = mag * sn;
+            }
+        };
+        if (OUT == OUT_S32 && WN % 64 == 0 && p.stage_epi && !(dbg & 8388608)) {
+            // Staged: two neighbouring blocks hold the 32 slots of one S32 group (128 bytes of a spectrum row, re and im each).
+            // The 32 x 32-slot tile goes through the wave's LDS scratch in the S32 row image and leaves as full lines, like
+            // the staged epilogue of the hot layers below (direct form: 8-byte pieces, 16 stores per block)
+            char* sc = smem_s + p.stage_off + wave * 4096;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jp = 0; jp + 1 < TN; jp += 2) {
+                    const int n0 = n_w + jp * 32;
+                    if (n0 >= p.N) continue;                       // wave-uniform; N % 64 == 0 (host)
+                    f32x4 re[4], im[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) head_run(i, jp + (k >> 1), k & 1, re[k], im[k]);
+#pragma unroll
+                    for (int pz = 0; pz < 2; ++pz) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int sk = MF ? 2 * (k & 1) : (k & 1);
+                            const int rw = sub_row(sk), cw = 16 * (k >> 1) + (sub_col(sk) & 15), sww = (rw >> 1) & 7;
+                            const f32x4 v = pz ? im[k] : re[k];
+                            amax = amax4(amax, v.x, v.y, v.z, v.w);
+                            f16x4 hi, lo;
+                            split4_f16(v.x, v.y, v.z, v.w, hi, lo);
+                            *reinterpret_cast<f16x4*>(sc + rw * 128 + (((cw >> 3) ^ sww) * 16) + 2 * (cw & 7)) = hi;
+                            *reinterpret_cast<f16x4*>(sc + rw * 128 + (((4 + (cw >> 3)) ^ sww) * 16) + 2 * (cw & 7)) = lo;
+                        }
+                        f32x4 q[4];
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) {
+                            const int r = 8 * it + (lane >> 3), ch = lane & 7;
+                            q[it] = *reinterpret_cast<const f32x4*>(sc + r * 128 + ((ch ^ ((r >> 1) & 7)) * 16));
+                        }
+                        const int f0 = (n0 >> 6) * 32 + pz * p.head_kb;           // first slot of the group, as a float index of the row
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) {
+                            const int r = 8 * it + (lane >> 3), ch = lane & 7;
+                            const int m = m_w + i * 32 + r;
+                            if (m < p.M && !(dbg & 128)) store_c16<!(dbg & 4096)>(Cg + (long)m * p.c_rstride + f0 + 4 * ch, q[it]);
+                        }
+                    }
+                }
+        } else
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int j = 0; j + 1 < TN; j += 2)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int m = m_w + i * 32 + sub_row(g);
-                    const int pc = n_w + j * 32 + sub_col(g);         // packed row of the log-magnitude; phase 32 later
+                for (int h = 0; h < 2; ++h) {
+                    const int s = MF ? 2 * h : h;
+                    const int m = m_w + i * 32 + sub_row(s);
+                    const int pc = n_w + j * 32 + sub_col(s);
                     if (m >= p.M || pc >= p.N) continue;
                     float* crow = Cg + (long)m * p.c_rstride;
-                    const f32x4 bmag = *reinterpret_cast<const f32x4*>(p.bias + pc);
-                    const f32x4 bph = *reinterpret_cast<const f32x4*>(p.bias + pc + 32);
-                    const f32x4 lm = acc4(i, j, g) + bmag, ph = acc4(i, j + 1, g) + bph;
                     f32x4 re, im;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float mag = fminf(expf(lm[e]), 100.f);                 // heads.py:55-56
-                        float sn, cs;
-                        sincosf(ph[e], &sn, &cs);                                    // one range reduction for both
-                        re[e] = mag * cs;
-                        im[e] = mag * sn;
-                    }
-                    const int f = (pc >> 6) * 32 + (pc & 31);          // bin slot
-                    if (OUT == OUT_S32) {
+                    head_run(i, j, h, re, im);
+                    const int f = (pc >> 5) * 16 + (pc & 15);          // spectrum slot
+                    if (dbg & 128) {           // timing experiment: no stores
+                        amax = amax4(amax4(amax, re.x, re.y, re.z, re.w), im.x, im.y, im.z, im.w);
+                    } else if (OUT == OUT_S32) {
                         store_s32_x4(crow, f, re, amax);
                         store_s32_x4(crow, p.head_kb + f, im, amax);
                     } else {
@@ -1000,7 +1084,7 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
     GemmArgs b = a;
     {   // per-wave bias (+ gamma) cache: WN floats each, filled by DMA at the top of every output tile
         constexpr bool pcache = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ELU || EPI == EPI_BIAS_RES ||
-                                EPI == EPI_BIAS_RES_ELU || EPI == EPI_BIAS_GAMMA_RES;
+                                EPI == EPI_BIAS_RES_ELU || EPI == EPI_BIAS_GAMMA_RES || EPI == EPI_HEAD;
         constexpr size_t pc_bytes = (size_t)WMs * WNs * (BN / WNs) * 4 * (EPI == EPI_BIAS_GAMMA_RES ? 2 : 1);
         const size_t off = (smem + 127) / 128 * 128;
         if (pcache && (a.bias || EPI == EPI_BIAS_GAMMA_RES)) {
@@ -1011,12 +1095,15 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
         }
     }
     {   // staged epilogue: 4 KB of scratch per wave after the stages and tables, when it fits and the layout allows
+        // (the head pairs two 32-column blocks into one 32-slot S32 group: wave tiles of whole 64-column pairs, N % 64 == 0)
         constexpr bool can_stage = ((OUT == OUT_F32 || OUT == OUT_S32_DUAL_ELU || OUT == OUT_F32_AND_S32) && EPI == EPI_BIAS) ||
-                                   (OUT == OUT_S32 && (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ELU));
+                                   (OUT == OUT_S32 && (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ELU)) ||
+                                   (OUT == OUT_S32 && EPI == EPI_HEAD && (BN / WNs) % 64 == 0);
         const size_t off = (smem + 127) / 128 * 128;
         const char* ns = getenv("WT_GEMM16S_NOSTAGE");
         constexpr bool dual = OUT == OUT_S32_DUAL_ELU || OUT == OUT_F32_AND_S32;
-        if (can_stage && off + (size_t)WMs * WNs * 4096 <= smem_cap && a.N % 32 == 0 && !(ns && ns[0] == '1') &&
+        if (can_stage && off + (size_t)WMs * WNs * 4096 <= smem_cap && a.N % (EPI == EPI_HEAD ? 64 : 32) == 0 &&
+            !(EPI == EPI_HEAD && (a.head_kb % 32 || a.c_rstride % 32)) && !(ns && ns[0] == '1') &&
             !(dual && ns && ns[0] == '2')) {
             b.stage_epi = 1; b.stage_off = (int)off;
             smem = off + (size_t)WMs * WNs * 4096;
@@ -1037,7 +1124,9 @@ static int tile16s_override() {
 template <int EPI, int OUT>
 static int launch16s_tiled(const GemmArgs& a, hipStream_t s) {
     if constexpr (EPI == EPI_HEAD) {
-        return launch16s_one<128, 128, 4, 2, 3, EPI, OUT>(a, s);      // wave tile 32x64: paired column tiles
+        // wave tile 32 x 64: one whole 32-slot group per row block, staged full-line stores.  (7680 x 2432: 1140 tiles in 5
+        // rounds of 232; 128 x 192 tiles need 4 rounds of 1.5 x the work each: 134 vs 127 us, tools/micro/gemm_lab.hip)
+        return launch16s_one<128, 128, 4, 2, 3, EPI, OUT>(a, s);
     } else if constexpr (EPI == EPI_ARGMAX) {
         return launch16s_one<128, 192, 4, 2, 3, EPI, OUT>(a, s);      // gemm16s_vq_parts() assumes this tile
     } else {
@@ -1104,6 +1193,7 @@ int launch_gemm16s(const GemmArgs& a_in, int epi, int out, hipStream_t s) {
     if (const char* e = getenv("WT_GEMM16S_GM")) a.group_m = atoi(e) > 0 ? atoi(e) : a.group_m;      // sweeps (tools/gemm16s_bench.py)
     if (const char* e = getenv("WT_GEMM16S_GN")) a.group_n = atoi(e);
     if ((out == OUT_S32_DUAL_ELU || out == OUT_F32_AND_S32) && !c.C2) { set_error("gemm16s: this output format needs C2"); return -1; }
+    if (epi == EPI_HEAD && (!c.bias || c.N % 32 || c.head_kb <= 0)) { set_error("gemm16s: head epilogue needs a bias, N % 32 == 0 and head_kb"); return -1; }
     if (epi == EPI_ARGMAX && (!c.vq_xx || !c.vq_ee || !c.vq_pval || !c.vq_pidx || c.vq_nparts != gemm16s_vq_parts(c.N))) {
         set_error("gemm16s: argmax epilogue needs xx, ee and (value, index) slots for gemm16s_vq_parts(N) parts"); return -1;
     }

@@ -313,12 +313,13 @@ int build_model(wt_model* M, TensorMap& tm) {
         if (!w || !b || !win) return WT_ERR_MISSING_TENSOR;
         // spectrum slot s -> frequency bin: s < Kq: even bin 2s; else odd bin 2(s-Kq)+1 (-1 = padding)
         auto slot_bin = [&](int s) { int f = s < Kq ? 2 * s : 2 * (s - Kq) + 1; return f <= N / 2 && (s < Kq || s - Kq < Q) ? f : -1; };
-        // packed head rows: 64-row groups = 32 log-magnitude rows then the 32 phase rows of the same slots
+        // packed head rows: 32-row groups = 16 log-magnitude rows then the 16 phase rows of the same slots (a 32 x 32 block
+        // of any GEMM tile then holds both halves of 16 slots: no constraint on the tile width)
         std::vector<float> wp((size_t)2 * Kb * D, 0.f), bp((size_t)2 * Kb, 0.f);
         for (int sl = 0; sl < Kb; ++sl) {
             const int f = slot_bin(sl);
             if (f < 0) continue;
-            const size_t pm = (size_t)(sl / 32) * 64 + (sl % 32), pp = pm + 32;
+            const size_t pm = (size_t)(sl / 16) * 32 + (sl % 16), pp = pm + 16;
             std::memcpy(&wp[pm * D], &w[(size_t)f * D], D * sizeof(float));
             std::memcpy(&wp[pp * D], &w[(size_t)(bins + f) * D], D * sizeof(float));
             bp[pm] = b[f];
@@ -531,7 +532,7 @@ int build_splits(wt_model* M) {
 // header (magic, version, the wt_arch and a hash of it) and the model struct with every pointer written as
 // (allocation index).  Loading it is allocate + upload + fix up pointers: nothing is folded, packed or split again.
 static constexpr uint32_t PACK_MAGIC = 0x4b505457u;     // "WTPK"
-static constexpr int32_t PACK_VERSION = 5;
+static constexpr int32_t PACK_VERSION = 6;
 
 static uint64_t arch_hash_of(const wt_arch& a) {        // FNV-1a over the architecture struct and the layout version
     uint64_t h = 1469598103934665603ull;

@@ -218,8 +218,16 @@ class _Engine:
         used = lib.wt_packed_bytes(buf.ctypes.data_as(ctypes.c_void_p), n)       # wt_model_export_bytes is an upper bound
         return buf[:used] if 0 < used <= n else buf
 
+    @staticmethod
+    def _key(kind: int, B: int, length: int, flags: int, device) -> tuple:
+        """A plan owns a workspace, so it serves ONE stream: calls made under another current stream than the default one
+        get plans (and staging buffers) of their own, keyed (..., stream handle).  Two streams can then run the same model
+        side by side (sharding.StepRunner(lanes=2)); the library orders their persistent LSTM launches itself (capi.cpp)."""
+        sp = torch.cuda.current_stream(device).cuda_stream if device is not None else 0
+        return (kind, B, length, flags) if not sp else (kind, B, length, flags, sp)
+
     def plan(self, kind: int, B: int, length: int, flags: int, device: torch.device):
-        key = (kind, B, length, flags)
+        key = self._key(kind, B, length, flags, device)
         hit = self.plans.pop(key, None)
         if hit is not None:
             self.plans[key] = hit                     # most recently used last (dicts keep insertion order)
@@ -242,10 +250,10 @@ class _Engine:
             lib.wt_plan_destroy(self.plans.pop(k)[0])
             self.io.pop(k, None)
 
-    def staging(self, kind: int, B: int, length: int, flags: int, make) -> Dict[str, torch.Tensor]:
+    def staging(self, kind: int, B: int, length: int, flags: int, make, device=None) -> Dict[str, torch.Tensor]:
         """Fixed input/output tensors of a graph plan: a recorded hipGraph replays fixed addresses, so calls copy their
         input in and hand out copies of the results (a few hundred KB at the batch sizes graphs are used for)."""
-        key = (kind, B, length, flags)
+        key = self._key(kind, B, length, flags, device)
         io = self.io.get(key)
         if io is None:
             io = self.io[key] = make()
@@ -617,7 +625,7 @@ class WavTokenizer(nn.Module):
                     "in": torch.empty((B, T), dtype=torch.float32, device=dev),
                     "feats": torch.empty((B, 512, L), dtype=torch.float32, device=dev),
                     "codes": torch.empty((1, B, L), dtype=torch.int64, device=dev),
-                    "emb": torch.empty((B, 512, L), dtype=torch.float32, device=dev)})
+                    "emb": torch.empty((B, 512, L), dtype=torch.float32, device=dev)}, dev)
                 io["in"].copy_(audio)
                 check(lib.wt_encode(plan, _ptr(io["in"]), _ptr(io["feats"]), _ptr(io["codes"]), _ptr(io["emb"]), _ptr(ws),
                                     _stream_ptr(dev)), "wt_encode")
@@ -666,7 +674,7 @@ class WavTokenizer(nn.Module):
             if flags & _capi.WT_PLAN_FLAG_GRAPH:
                 io = self._engine.staging(_capi.WT_PLAN_DECODE, B, L, flags, lambda: {
                     "in": torch.empty((B, self._arch.input_channels, L), dtype=torch.float32, device=dev),
-                    "wav": torch.empty((B, self._wave_len(L)), dtype=torch.float32, device=dev)})
+                    "wav": torch.empty((B, self._wave_len(L)), dtype=torch.float32, device=dev)}, dev)
                 io["in"].copy_(features)
                 check(lib.wt_decode(plan, _ptr(io["in"]), bw, _ptr(io["wav"]), _ptr(None), _ptr(ws), _stream_ptr(dev)), "wt_decode")
                 return io["wav"].clone(), None

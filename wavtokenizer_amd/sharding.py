@@ -122,10 +122,18 @@ class StepRunner:
     (wavtokenizer_amd/csrc/lstm_persist.hip).  `log`, when given, receives (event, step) tuples in host order:
     "encode", "issue", "decode", "collect" - the tests assert the invariant on it."""
 
-    def __init__(self, model, wav, bw, dist, world, rank, gather=True, backend="nccl", dst=0, log=None):
+    def __init__(self, model, wav, bw, dist, world, rank, gather=True, backend="nccl", dst=0, log=None, lanes=1):
         self.model, self.wav, self.bw = model, wav, bw
         self.dist, self.world, self.rank, self.backend, self.dst = dist, world, rank, backend, dst
         self.gather = bool(gather) and world > 1
+        # lanes > 1 (only without the exchange): step i runs on HIP stream i % lanes, so step i+1's encode_infer runs beside
+        # step i's decode and fills the launch gaps and last-round tails of its kernels.  The model keeps a plan + workspace
+        # per stream (pretrained._Engine._key) and the library chains the persistent LSTM launches of different streams
+        # (capi.cpp, LstmChain): at most one of them is on the GPU at a time.  Same kernels, same results.
+        if lanes > 1 and self.gather:
+            raise ValueError("lanes > 1 is the single-rank pipeline; the sharded exchange keeps one lane (DESIGN section 6)")
+        self.lanes = int(lanes)
+        self.streams = [torch.cuda.Stream(device=wav.device) for _ in range(self.lanes)] if self.lanes > 1 else None
         self.prev = None            # (step index, codes, waveform) of the previous step, not yet exchanged
         self.i = 0
         self.log = log
@@ -155,6 +163,13 @@ class StepRunner:
         return res
 
     def step(self):
+        if self.streams is not None:
+            st = self.streams[self.i % self.lanes]
+            self.i += 1
+            with torch.cuda.stream(st):
+                feats, codes = self.model.encode_infer(self.wav, bandwidth_id=self.bw)
+                out = self.model.decode(feats, bandwidth_id=self.bw)
+            return codes, out, None
         i = self.i
         self.i += 1
         feats, codes = self.model.encode_infer(self.wav, bandwidth_id=self.bw)
@@ -168,7 +183,13 @@ class StepRunner:
         return codes, out, res
 
     def drain(self):
-        """The exchange of the last step: issued and collected here (inside the timed region of bench.py)."""
+        """The exchange of the last step: issued and collected here (inside the timed region of bench.py).  With lanes the
+        caller's stream is made to wait for every lane (bench.py synchronises the device right after)."""
+        if self.streams is not None:
+            cur = torch.cuda.current_stream(self.wav.device)
+            for st in self.streams:
+                cur.wait_stream(st)
+            return None
         if self.gather and self.prev is not None:
             return self._collect(self._issue())
         return None
