@@ -16,7 +16,10 @@
  *   - a wt_model is immutable after creation (folded + packed weights in HBM) and may be shared
  *     by host threads.  A wt_plan may be shared too: host calls on one plan are serialised by a
  *     per-plan lock (they only enqueue), and calls that may be in flight on the GPU at the same
- *     time need distinct workspaces (the call's status word lives in the workspace).
+ *     time (two streams) need a plan and a workspace each (stage buffers and the call's status
+ *     word live in the workspace).  Calls that launch the persistent LSTM kernel are chained per
+ *     device by the library: one made on another stream than the previous one first waits on the
+ *     GPU for that previous call (two such launches must never share the CUs).
  *   - a call that fails ON THE DEVICE (wt_status_bits) never hands out plausible data: the guard
  *     step that ends every plan overwrites its outputs (codes = -1, floats = NaN), and the next
  *     host call on ANY plan of the same model returns the matching error once, without running
