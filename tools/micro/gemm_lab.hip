@@ -101,6 +101,8 @@ int main(int argc, char** argv) {
                   {"  r03 + setprio", run128x192<EPI_BIAS_GELU, OUT_S32, 8192>},
                   {"no epilogue + in-loop fake drain", run128x192<EPI_BIAS_GELU, OUT_S32, 4 + 2097152>},
                   {"r03 + in-loop fake drain", run128x192<EPI_BIAS_GELU, OUT_S32, 2097152>},
+                  {"no epilogue + fake drain, SIMD partners in opposite halves", run128x192<EPI_BIAS_GELU, OUT_S32, 4 + 2097152 + 16777216>},
+                  {"r03 + fake drain, SIMD partners in opposite halves", run128x192<EPI_BIAS_GELU, OUT_S32, 2097152 + 16777216>},
                   {"epilogue without GELU", run128x192<EPI_BIAS_GELU, OUT_S32, 512>},
                   {"epilogue without global stores", run128x192<EPI_BIAS_GELU, OUT_S32, 128>},
                   {"epilogue without GELU and stores", run128x192<EPI_BIAS_GELU, OUT_S32, 512 + 128>},

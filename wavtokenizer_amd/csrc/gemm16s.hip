@@ -616,9 +616,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
                 if (!(dbg & 16)) read_frags(rs, 1, F1);
                 if (!(dbg & 2)) mfma_block(F0);
             }
-            if constexpr ((dbg & 2097152) != 0) {
-                // timing experiment: what an epilogue drained inside the K loop would cost - per K step the GELU + split of one
-                // 4-column run and its two 8-byte stores (out of range: counted, dropped), scheduled among the MFMAs
+            // timing experiment: what an epilogue drained inside the K loop would cost - per K step the GELU + split of one
+            // 4-column run and its two 8-byte stores (out of range: counted, dropped), scheduled among the MFMAs.  With bit
+            // 16777216 the two waves of a SIMD drain in different halves of the step (waves 0-3 after the barrier, 4-7 in front
+            // of it), so that one wave's vector work meets the other's MFMAs
+            auto fake_drain = [&]() {
                 fake = gelu_erfc_s4(fake + (f32x4){1e-3f, 2e-3f, 3e-3f, 4e-3f});
                 f16x4 fh, fl;
                 split4_f16(fake.x, fake.y, fake.z, fake.w, fh, fl);
@@ -626,12 +628,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
                 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, fh), rsFake, (int)0x7ffffff0, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, fl), rsFake, (int)0x7ffffff0, 0, 0);
+            };
+            if constexpr ((dbg & 2097152) != 0) {
+                if (!(dbg & 16777216) || wave >= NW / 2) fake_drain();
             }
             if (dbg & 32768) { if (!(dbg & 32)) wait_vm_lgkm<63>(); }                 // timing experiment: DMA issued, never waited for (races)
-            else if (!(dbg & 32)) wait_vm_lgkm<(NSTAGE - 2) * NPT + ((dbg & 2097152) ? 2 : 0)>();
+            else if (!(dbg & 32)) {
+                // (the drain's two stores are younger than this step's DMA pieces only where they were issued behind them)
+                if ((dbg & 2097152) && (!(dbg & 16777216) || wave >= NW / 2)) wait_vm_lgkm<(NSTAGE - 2) * NPT + 2>();
+                else wait_vm_lgkm<(NSTAGE - 2) * NPT>();
+            }
             if (!(dbg & 8)) __builtin_amdgcn_s_barrier();
             rs = rs + 1 == NSTAGE ? 0 : rs + 1;
             ws = ws + 1 == NSTAGE ? 0 : ws + 1;
+            if constexpr ((dbg & 2097152) != 0 && (dbg & 16777216) != 0) {
+                if (wave < NW / 2) fake_drain();
+            }
             if (MF) {
                 if (!(dbg & 16)) read_b16(rs, 0, F0b);       // after the very last step: a harmless read of a zero-filled stage
                 if (dbg & 8192) __builtin_amdgcn_s_setprio(1);
