@@ -446,3 +446,14 @@ def test_no_kernel_spills_or_scratch():
         if t.get("private_segment_fixed_size", 0) and not any(a in name for a in allowed_scratch):
             bad.append((name, "private_segment_fixed_size", t["private_segment_fixed_size"]))
     assert not bad, bad
+
+
+def test_step_runner_lanes_are_single_rank_only():
+    """lanes > 1 (steps in flight on separate HIP streams) is the single-rank pipeline: together with the sharded exchange the
+    runner refuses it, so the N = 1 and N > 1 bench lines always measure the same schedule."""
+    from wavtokenizer_amd.sharding import StepRunner
+    wav = torch.zeros((2, 16))
+    with pytest.raises(ValueError, match="lanes"):
+        StepRunner(object(), wav, torch.tensor([0]), object(), 2, 0, gather=True, backend="gloo", lanes=2)
+    r = StepRunner(object(), wav, torch.tensor([0]), None, 1, 0, gather=True, lanes=1)      # world 1: no exchange, one lane
+    assert r.lanes == 1 and r.streams is None and not r.gather
