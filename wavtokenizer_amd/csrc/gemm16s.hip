@@ -1201,8 +1201,14 @@ int launch_gemm16s(const GemmArgs& a_in, int epi, int out, hipStream_t s) {
         }
     }
     GemmArgs a = a_in;
-    a.group_m = (a.N + 191) / 192 > 8 ? 8 : 1;
-    if (const char* e = getenv("WT_GEMM16S_GM")) a.group_m = atoi(e) > 0 ? atoi(e) : a.group_m;      // sweeps (tools/gemm16s_bench.py)
+    // Tile order.  An XCD runs 30 tiles at a time (240 persistent workgroups / 8); a round pulls the A panels of its row tiles
+    // and the W panels of its column tiles through that XCD's L2 once.  Wide outputs (ConvNeXt pwconv1: 60 x 12 tiles) walk
+    // blocks of 5 row x 6 column tiles = one XCD round each: 132 MB read per launch instead of 156 with groups of 8 row
+    // tiles over all 12 columns, at the same launch time (profiles/r03_gmn_traffic.txt; DESIGN section 3 has the 127 MB floor)
+    const int tiles_n192 = (a.N + 191) / 192;
+    a.group_m = tiles_n192 > 8 ? 8 : 1;
+    if (tiles_n192 >= 12 && tiles_n192 % 6 == 0 && a.nz == 1) { a.group_m = 5; a.group_n = 6; }
+    if (const char* e = getenv("WT_GEMM16S_GM")) { a.group_m = atoi(e) > 0 ? atoi(e) : a.group_m; a.group_n = 0; }      // sweeps (tools/gemm16s_bench.py)
     if (const char* e = getenv("WT_GEMM16S_GN")) a.group_n = atoi(e);
     if ((out == OUT_S32_DUAL_ELU || out == OUT_F32_AND_S32) && !c.C2) { set_error("gemm16s: this output format needs C2"); return -1; }
     if (epi == EPI_HEAD && (!c.bias || c.N % 32 || c.head_kb <= 0)) { set_error("gemm16s: head epilogue needs a bias, N % 32 == 0 and head_kb"); return -1; }
