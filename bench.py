@@ -17,8 +17,14 @@ the MEDIAN block (a single 0.13 s block is a thin basis: the min / max over the 
 
 Extra objects on the line:
   roofline      — dominant kernel (ConvNeXt pwconv1 GEMM + GELU, 12 launches per step): achieved =
-                  algorithmic 2*M*N*K per launch / mean launch duration, from HIP events recorded on the
-                  launch stream during the timed steps (wt_plan_set_timing).  The kernel evaluates every
+                  algorithmic 2*M*N*K per launch / mean launch duration of those launches during the timed
+                  steps.  The duration is taken ON THE DEVICE (wt_plan_set_timing("@cnx.pwconv1"): every
+                  workgroup of the launch reads the constant 100 MHz clock on entry and exit; earliest entry
+                  to latest exit), not between HIP events: an event record is a packet of its own, costs
+                  4-7 us between two launches and is counted into the bracket (94.6 us between events
+                  against 88.7 us in the rocprofv3 trace of the same run; with the stamps 84.7 against 86.6,
+                  the difference being the dispatch latency rocprof counts: profiles/r03_trace_vs_stamps.txt),
+                  and 24 such packets per step also cost the step itself 2 %.  The kernel evaluates every
                   fp32-equivalent product with THREE v_mfma_f32_32x32x16_f16 (split-f16, gemm16s.hip), so
                   its MFMA roofline in algorithmic (fp32-equivalent) FLOP/s is the dense f16 peak / 3.
   cpu_baseline  — the oracle (oracle/cpu_ref.py, same ATen op sequence as the reference) timed on
@@ -241,7 +247,7 @@ def main():
     runner.step()                                                  # creates the plans
     runner.drain()
     dplan = next(p for k, (p, _w) in model._engine.plans.items() if k[:4] == (_capi.WT_PLAN_DECODE, B, L, model._graph_flags(B)))
-    blocks, kern = run_blocks(runner, args.steps, max(0, args.warmup - 1), args.repeats, (dplan, b"cnx.pwconv1"))
+    blocks, kern = run_blocks(runner, args.steps, max(0, args.warmup - 1), args.repeats, (dplan, b"cnx.pwconv1" if os.environ.get("WT_BENCH_TIMING") == "events" else b"@cnx.pwconv1"))     # (events: tools/trace_vs_events.sh only)
     model.check_status()
     own_blocks = list(runner.own_blocks)
 
@@ -317,6 +323,9 @@ def main():
                                       "issues %.0f TF/s of f16 MFMA work" % (PEAK_F16_MFMA_TFLOPS, 3 * achieved),
                          "algorithmic_bytes_per_launch": 4 * (Mrows * arch.dim + arch.intermediate_dim * arch.dim + Mrows * arch.intermediate_dim),
                          "flops_per_launch": flops, "avg_launch_ms": round(kern_ms, 4), "launches_timed": kern[1],
+                         "launch_timing": "device clock (s_memrealtime, 100 MHz) of the launch's first workgroup entry to its last exit, every "
+                                          "pwconv1 launch of the timed steps; no events in the stream (profiles/r03_trace_vs_stamps.txt compares it "
+                                          "with the rocprofv3 trace and with bracketing HIP events in one run)",
                          "end_to_end_tflops": round(e2e_tflops, 2),
                          "end_to_end_frac": round(e2e_tflops / PEAK_F16X3_TFLOPS, 4)},
         }

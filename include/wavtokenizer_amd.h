@@ -165,8 +165,12 @@ int    wt_plan_buffer_name(const wt_plan* p, int32_t index, const char** name);
 
 /* Measurement hook (bench.py's roofline leg; no counterpart in the reference): HIP events are
  * recorded on the call's stream around every step whose name contains `name_substr` ("" / NULL
- * turns it off).  wt_plan_read_timing waits for the recorded events and returns the summed
- * milliseconds and the number of timed launches since the last reset.  Not thread-safe. */
+ * turns it off).  A leading '@' ("@cnx.pwconv1") uses no events: the step's gemm16s launch
+ * records its own duration on the device (every workgroup takes the constant 100 MHz clock on
+ * entry and exit; earliest entry to latest exit), so no packet is added between the launches (an
+ * event record costs 4-7 us there and is counted into the bracket).  wt_plan_read_timing waits
+ * for the work and returns the summed milliseconds and the number of timed launches since the
+ * last reset.  Not thread-safe. */
 int wt_plan_num_steps(const wt_plan* p);
 int wt_plan_step_name(const wt_plan* p, int32_t index, const char** name);
 int wt_plan_set_timing(const wt_plan* p, const char* name_substr);

@@ -45,7 +45,15 @@ struct PerDeviceOnce {
 enum : unsigned { WT_STATUS_LSTM = 1u, WT_STATUS_RANGE = 2u };
 // The launch functions below take the status pointer from this per-thread context, which run_plan sets for the
 // duration of a call (nullptr outside a plan: the single-stage entry points have no status word)
-struct LaunchCtx { unsigned* status = nullptr; };
+// stamp_start / stamp_end: when set (wt_plan_set_timing("@name")), the next gemm16s launch records its own duration on the
+// device: every workgroup takes the constant 100 MHz clock (s_memrealtime) on entry and on exit, atomic min / max into the two
+// words; stamp_used reports that a launch took them.  No packet is added to the stream, so the neighbours do not move
+struct LaunchCtx {
+    unsigned* status = nullptr;
+    unsigned long long* stamp_start = nullptr;
+    unsigned long long* stamp_end = nullptr;
+    bool stamp_used = false;
+};
 extern thread_local LaunchCtx g_launch;
 
 #if defined(__HIPCC__)
@@ -176,6 +184,8 @@ struct GemmArgs {
     int group_n = 0;      // gemm16s: column tiles per scheduling block (0 = all): an XCD's share of tiles then spans fewer weight panels
     int tap_pair = 0;     // gemm16s: K slot q holds tap (q >> 1) + (q & 1) * stride (k = 2 * stride convs; weights packed alike):
                           // the two output frames that share an input frame read it in adjacent K steps (L2 hit, not a re-fetch)
+    unsigned long long* stamp_start = nullptr;   // gemm16s timing hook (LaunchCtx): device clock of the first entry / last exit
+    unsigned long long* stamp_end = nullptr;
     int stage_epi = 0;    // gemm16s: epilogue staged through per-wave LDS scratch at byte offset stage_off (set by the launcher)
     int stage_off = 0;
     int pc_off = 0;       // gemm16s: byte offset of the per-wave bias (and gamma) cache in LDS, 0 = vectors read from global memory

@@ -253,6 +253,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int ntiles = tiles_m * tiles_n;
     const int G = gridDim.x;                 // persistent: this workgroup owns tiles blockIdx.x, + G, + 2G, ...
+    if (p.stamp_start && tid == 0)           // timing hook: earliest entry of any workgroup (constant 100 MHz clock)
+        __hip_atomic_fetch_min(p.stamp_start, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int z = blockIdx.z;
     const int nclips = p.M / p.T_out;
     constexpr unsigned OOB = 0x80000000u;
@@ -958,6 +960,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
         p.dbg_stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
     }
     range_report(p.status, amax);
+    if (p.stamp_end) {                       // ... and the latest exit, after every wave's stores have been acknowledged
+        wait_vm_lgkm<0>();
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_fetch_max(p.stamp_end, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     wait_vm_lgkm<0>();
 }
 
@@ -1122,6 +1130,10 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
         }
     }
     if (!b.status) b.status = g_launch.status;
+    if (g_launch.stamp_start && g_launch.stamp_end) {
+        b.stamp_start = g_launch.stamp_start; b.stamp_end = g_launch.stamp_end;
+        g_launch.stamp_used = true;
+    }
     hipLaunchKernelGGL(kern, dim3(G, 1, a.nz), dim3(64 * WMs * WNs), smem, s, b);
     WT_HIP_CHECK(hipGetLastError());
     return 0;

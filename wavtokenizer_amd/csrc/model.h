@@ -185,6 +185,10 @@ struct wt_plan {
     // leg); mutable profiling state, not thread-safe, off by default
     mutable std::string timing_filter;
     mutable std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending, ev_free;
+    // "@name" timing: device-side stamps of the gemm16s launches (capi.cpp): [0, STAMP_SLOTS) entry clocks, then exit clocks
+    static constexpr int STAMP_SLOTS = 8192;
+    mutable unsigned long long* stamps = nullptr;
+    mutable int stamp_next = 0;
     mutable double timing_ms = 0.0;
     mutable long timing_n = 0;
     // Call status (common.h WT_STATUS_*): the first 256 bytes of the workspace are the call's control block, whose word 0
@@ -216,6 +220,7 @@ struct wt_plan {
     wt_plan(const wt_plan&) = delete;
     ~wt_plan() {
         if (status_host) (void)hipHostFree(status_host);
+        if (stamps) (void)hipFree(stamps);
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
         for (auto& ev : ev_pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
