@@ -1307,3 +1307,41 @@ def test_two_lanes_match_one_stream(gpu_model):
         keys = [k for k in m._engine.plans if len(k) == 5 and k[1] == B]
         assert len({k[4] for k in keys}) == 2, keys                  # one plan set per lane stream
         m.check_status()
+
+
+def test_device_clock_timing_of_a_gemm_step(gpu_model):
+    """bench.py's roofline leg: wt_plan_set_timing("@name") makes the step's gemm16s launch stamp its own entry / exit on the
+    device clock (no events in the stream).  Every timed launch is counted once, the durations are sane and not larger than
+    what bracketing HIP events report for the same launches (those include the event packets), a step that is no gemm16s
+    launch is refused, and the results of a timed call are those of an untimed one."""
+    import ctypes
+    from wavtokenizer_amd import _capi, synth
+    lib = _capi.lib
+    name, m, _sd = gpu_model
+    B, T = 20, 24000
+    wav = torch.from_numpy(synth.make_clips(B, T, seed=5100)).cuda()
+    f, _c = m.encode_infer(wav, bandwidth_id=BW)
+    ref = m.decode(f, bandwidth_id=BW)
+    plan = next(p for k, (p, _w) in m._engine.plans.items() if k[0] == _capi.WT_PLAN_DECODE and k[1] == B)
+
+    def timed(flt, calls=3):
+        _capi.check(lib.wt_plan_set_timing(plan, flt), "set_timing")
+        outs = [m.decode(f, bandwidth_id=BW) for _ in range(calls)]
+        tot, n = ctypes.c_double(), ctypes.c_int64()
+        _capi.check(lib.wt_plan_read_timing(plan, ctypes.byref(tot), ctypes.byref(n), 1), "read_timing")
+        lib.wt_plan_set_timing(plan, b"")
+        return outs, tot.value, n.value
+
+    outs, ms_dev, n_dev = timed(b"@cnx.pwconv1")
+    assert n_dev == 3 * m._arch.num_layers
+    assert all(torch.equal(o, ref) for o in outs)
+    _outs, ms_ev, n_ev = timed(b"cnx.pwconv1")
+    assert n_ev == n_dev
+    per_dev, per_ev = ms_dev / n_dev, ms_ev / n_ev
+    assert 1e-3 < per_dev < 5.0 and per_dev < per_ev * 1.05, (per_dev, per_ev)
+    lib.wt_plan_set_timing(plan, b"@bb.cnx.norm")              # a row kernel, not a gemm16s launch
+    with pytest.raises(Exception, match="gemm16s"):
+        m.decode(f, bandwidth_id=BW)
+    lib.wt_plan_set_timing(plan, b"")
+    assert torch.equal(m.decode(f, bandwidth_id=BW), ref)
+    m.check_status()
