@@ -243,7 +243,9 @@ struct LstmChain {
     std::mutex mu;
     hipEvent_t ev = nullptr;
     hipStream_t last = nullptr;
-    bool have = false;
+    bool any = false;       // a call has been made
+    bool multi = false;     // calls have come from more than one stream: from then on every call records the event
+    bool have = false;      // ev marks the end of the previous call
 };
 static LstmChain g_lstm_chain[64];
 struct LstmChainScope {
@@ -255,13 +257,26 @@ struct LstmChainScope {
         ch = &g_lstm_chain[p->model->device];
         stream = s;
         ch->mu.lock();
-        if (ch->have && ch->last != s && hipStreamWaitEvent(s, ch->ev, 0) != hipSuccess) { set_error("hipStreamWaitEvent failed"); rc = WT_ERR_HIP; }
+        if (!ch->any || ch->last == s) return;
+        if (!ch->ev && hipEventCreateWithFlags(&ch->ev, hipEventDisableTiming) != hipSuccess) { ch->ev = nullptr; return; }
+        if (!ch->multi) {
+            // first call from a second stream.  Single-stream callers never pay for an event record (it is a packet of its own
+            // in the stream: 4-7 us), so there is none behind the previous call: order this one behind everything that stream
+            // holds right now instead (conservative, once), and record from here on
+            ch->multi = true;
+            ch->have = hipEventRecord(ch->ev, ch->last) == hipSuccess;
+            if (!ch->have) (void)hipGetLastError();      // (the stream may be gone: then so is its work)
+        }
+        if (ch->have && hipStreamWaitEvent(s, ch->ev, 0) != hipSuccess) { set_error("hipStreamWaitEvent failed"); rc = WT_ERR_HIP; }
     }
     ~LstmChainScope() {
         if (!ch) return;
-        if (!ch->ev && hipEventCreateWithFlags(&ch->ev, hipEventDisableTiming) != hipSuccess) ch->ev = nullptr;
-        ch->have = ch->ev && hipEventRecord(ch->ev, stream) == hipSuccess;
+        if (ch->multi) {
+            if (!ch->ev && hipEventCreateWithFlags(&ch->ev, hipEventDisableTiming) != hipSuccess) ch->ev = nullptr;
+            ch->have = ch->ev && hipEventRecord(ch->ev, stream) == hipSuccess;
+        }
         ch->last = stream;
+        ch->any = true;
         ch->mu.unlock();
     }
 };
