@@ -1322,7 +1322,7 @@ def test_device_clock_timing_of_a_gemm_step(gpu_model):
     wav = torch.from_numpy(synth.make_clips(B, T, seed=5100)).cuda()
     f, _c = m.encode_infer(wav, bandwidth_id=BW)
     ref = m.decode(f, bandwidth_id=BW)
-    plan = next(p for k, (p, _w) in m._engine.plans.items() if k[0] == _capi.WT_PLAN_DECODE and k[1] == B)
+    plan = m._engine.plans[(_capi.WT_PLAN_DECODE, B, f.shape[2], m._graph_flags(B))][0]
 
     def timed(flt, calls=3):
         _capi.check(lib.wt_plan_set_timing(plan, flt), "set_timing")
