@@ -231,9 +231,15 @@ __device__ __forceinline__ void wait_vm_lgkm() {
 #ifndef WT_GEMM16S_MF
 #define WT_GEMM16S_MF 1          // MFMA shape of every instantiation (0: 32x32x16, for A/B timing builds; 1: 16x16x32)
 #endif
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int EPI, int OUT, int DBG = 0, int MF = WT_GEMM16S_MF, int WPS = 2>
+// KS: K tiles per barrier.  1 = the pipeline described at the loop (one barrier in the middle of every K step).  2 = the
+// small-problem form (a handful of narrow tiles, one wave per SIMD): two K tiles are made visible by one barrier and their
+// fragment reads and MFMAs run back to back - such a launch is a chain of DMA-wait, barrier, LDS-read and MFMA latencies per
+// barrier, not of work (tools/step_times.py at B = 1), so half the barriers is most of the time.  Every accumulator still
+// sees its K tiles in ascending order: results are bit-identical to KS = 1
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int EPI, int OUT, int DBG = 0, int MF = WT_GEMM16S_MF, int WPS = 2, int KS = 1>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(const GemmArgs p) {
     constexpr int dbg = DBG;
+    static_assert(KS == 1 || (KS == 2 && NSTAGE == 6 && MF == 1 && DBG == 0), "two K tiles per barrier: 6 stages (three pairs), 16x16x32 MFMA, no experiment masks");
     constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -554,16 +560,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
     __syncthreads();
     loader_set_tile(blockIdx.x, 0);
 #pragma unroll
-    for (int s = 0; s < NSTAGE - 1; ++s) load_tile(s);       // needs nk >= NSTAGE - 1 when a next tile exists (host)
-    wait_vm_lgkm<(NSTAGE - 2) * NPT>();
+    for (int s = 0; s < (KS == 2 ? 4 : NSTAGE - 1); ++s) load_tile(s);       // needs nk >= NSTAGE - 1 when a next tile exists (host)
+    if (KS == 2) wait_vm_lgkm<2 * NPT>(); else wait_vm_lgkm<(NSTAGE - 2) * NPT>();
     __builtin_amdgcn_s_barrier();
     Frags F0, F1;
     FragA Fa;
     FragB F0b, F1b;
     if (MF) { read_a16(0, Fa); read_b16(0, 0, F0b); }
     else read_frags(0, 0, F0);
-    int rs = 0, ws = NSTAGE - 1;
+    int rs = 0, ws = KS == 2 ? 4 : NSTAGE - 1;
     int c_par = 0;
+    FragA Fa2;           // KS = 2: fragments of the second K tile of a pair
+    FragB F0b2;
     for (int vb = blockIdx.x; vb < ntiles; vb += G, c_par ^= 1) {
         // the table of this workgroup's next output tile: the loader turns to it NSTAGE-1 steps before this tile's
         // K loop ends, i.e. after at least one of the barriers below (host: nk >= NSTAGE + 1 in persistent launches)
@@ -593,6 +601,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { accm[MF ? 0 : i][MF ? 0 : j][r] = 0.f; accc[MF ? 0 : i][MF ? 0 : j][r] = 0.f; }
         }
+        if constexpr (KS == 2) {
+            // K tiles kt, kt + 1 (stages rs, rs + 1) are resident and visible; the next pair is in flight since the previous
+            // iteration and is waited for at the bottom of this one; the pair after it is requested now.  nk is even (host)
+            for (int kt = 0; kt < nk; kt += 2) {
+                const int rs1 = rs + 1;                          // rs is even, < 6
+                load_tile(ws);
+                load_tile(ws + 1);
+                read_b16(rs, 1, F1b);
+                mfma16_block(Fa, F0b, std::integral_constant<int, 0>{}, [](int) {});
+                read_a16(rs1, Fa2);
+                read_b16(rs1, 0, F0b2);
+                mfma16_block(Fa, F1b, std::integral_constant<int, 1>{}, [](int) {});
+                read_b16(rs1, 1, F1b);
+                mfma16_block(Fa2, F0b2, std::integral_constant<int, 0>{}, [](int) {});
+                wait_vm_lgkm<2 * NPT>();     // all but the pair just requested; and this wave's LDS reads (their stages are the next DMA target)
+                __builtin_amdgcn_s_barrier();
+                rs = rs + 2 == 6 ? 0 : rs + 2;
+                ws = ws + 2 == 6 ? 0 : ws + 2;
+                read_a16(rs, Fa);            // first fragments of the next pair (after the last pair: of the next output tile)
+                read_b16(rs, 0, F0b);
+                mfma16_block(Fa2, F1b, std::integral_constant<int, 1>{}, [](int) {});
+            }
+        } else
         for (int kt = 0; kt < nk; ++kt) {
             // (tried: the younger half of the waves issuing its DMA pieces after the first-half MFMAs instead of before them,
             // so that one wave's DMA issue runs beside its SIMD partner's MFMAs: 5.79 vs 5.80 ms per step A/B on one box: nothing)
@@ -1043,8 +1074,9 @@ int launch_pow2_scales(const float* a, long na, const float* b, long nb, unsigne
 }
 
 // ---------------------------------------------------------------------------------- host side
-template <int BM, int BN, int WMs, int WNs, int NSTAGE, int EPI, int OUT, int WPS = 2, int LABDBG = 0>
+template <int BM, int BN, int WMs, int WNs, int NSTAGE, int EPI, int OUT, int WPS = 2, int LABDBG = 0, int KS = 1>
 static int launch16s_one(const GemmArgs& a, hipStream_t s) {
+    if (KS == 2 && ((a.K / SBK) % 2 || a.K / SBK < 6)) { set_error("gemm16s: two K tiles per barrier need an even number (>= 6) of K tiles"); return -1; }
     static PerDeviceOnce attr_once;
     constexpr size_t stage_bytes = (size_t)NSTAGE * (BM + BN) * 128;
     size_t smem = stage_bytes + 2ull * a.taps * BM * sizeof(unsigned) + (a.A2 ? 2ull * BM * sizeof(unsigned) : 0);
@@ -1054,10 +1086,10 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
     static_assert(stage_bytes + 2 * BM * sizeof(unsigned) <= smem_cap, "LDS budget");
     if (smem > smem_cap) { set_error("gemm16s: too many taps for this tile's LDS budget"); return -1; }
     using kern_t = void (*)(const GemmArgs);
-    kern_t kern = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, LABDBG, WT_GEMM16S_MF, WPS>;
+    kern_t kern = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, LABDBG, WT_GEMM16S_MF, WPS, KS>;
     // the timing-experiment builds exist for the tile the ConvNeXt GEMMs run on (tools/gemm16s_bench.py dbg): the masks of
     // the ablation ladder, each also with the clock stamps (+1024)
-    constexpr bool has_dbg = LABDBG == 0 && BM == 128 && BN == 192 && WMs == 4 && NSTAGE == 3 && ((EPI == EPI_BIAS && OUT == OUT_F32) || (EPI == EPI_BIAS_GELU && OUT == OUT_S32));
+    constexpr bool has_dbg = LABDBG == 0 && KS == 1 && BM == 128 && BN == 192 && WMs == 4 && NSTAGE == 3 && ((EPI == EPI_BIAS && OUT == OUT_F32) || (EPI == EPI_BIAS_GELU && OUT == OUT_S32));
     int dbg_req = 0;
     if (const char* e = getenv("WT_GEMM16S_DBG")) dbg_req = atoi(e);
     kern_t dbg_kerns[8] = {};
@@ -1078,7 +1110,7 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
         }
     }
     if (int rc = attr_once.run([&]() -> int {
-        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, LABDBG, WT_GEMM16S_MF, WPS>),
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, LABDBG, WT_GEMM16S_MF, WPS, KS>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max));
         for (int i = 0; i < 8; ++i)
             if (dbg_kerns[i]) WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dbg_kerns[i]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max));
@@ -1166,7 +1198,11 @@ static int launch16s_tiled(const GemmArgs& a, hipStream_t s) {
         // K loop alone, so the problem is cut into 32-column tiles instead (4x the workgroups, a third of the work per
         // K step).  Every tile shape accumulates K in the same order: results do not depend on the choice
         const long t128 = ((a.M + 127) / 128) * ((a.N + 127) / 128) * a.nz;
-        if (t128 <= 32) return launch16s_one<128, 32, 4, 1, 3, EPI, OUT>(a, s);
+        // ... and two K tiles per barrier where K allows (KS = 2: these launches are latency chains, see the kernel)
+        static const bool ks2_env = [] { const char* e = getenv("WT_GEMM16S_KS"); return !e || e[0] != '1'; }();
+        const int nkt = a.K / SBK;
+        const bool ks2 = ks2_env && nkt % 2 == 0 && nkt >= 6;
+        if (t128 <= 32) return ks2 ? launch16s_one<128, 32, 4, 1, 6, EPI, OUT, 2, 0, 2>(a, s) : launch16s_one<128, 32, 4, 1, 3, EPI, OUT>(a, s);
         if (t128 <= 100) return launch16s_one<128, 64, 4, 1, 3, EPI, OUT>(a, s);     // up to ~16 clips: 2x the workgroups
         // one 8-wave workgroup per CU (256 slots): 128x192 unless its last round would be mostly idle
         const long tm = (a.M + 127) / 128;
