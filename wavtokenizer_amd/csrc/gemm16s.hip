@@ -1202,7 +1202,10 @@ static int launch16s_tiled(const GemmArgs& a, hipStream_t s) {
         static const bool ks2_env = [] { const char* e = getenv("WT_GEMM16S_KS"); return !e || e[0] != '1'; }();
         const int nkt = a.K / SBK;
         const bool ks2 = ks2_env && nkt % 2 == 0 && nkt >= 6;
-        if (t128 <= 32) return ks2 ? launch16s_one<128, 32, 4, 1, 6, EPI, OUT, 2, 0, 2>(a, s) : launch16s_one<128, 32, 4, 1, 3, EPI, OUT>(a, s);
+        // (with it a 128 x 32 tile walks K faster than a 128 x 64 tile does: it is used as long as all of its tiles run at once)
+        const long t32 = ((a.M + 127) / 128) * ((a.N + 31) / 32) * a.nz;
+        if (ks2 && t32 <= 256) return launch16s_one<128, 32, 4, 1, 6, EPI, OUT, 2, 0, 2>(a, s);
+        if (t128 <= 32) return launch16s_one<128, 32, 4, 1, 3, EPI, OUT>(a, s);
         if (t128 <= 100) return launch16s_one<128, 64, 4, 1, 3, EPI, OUT>(a, s);     // up to ~16 clips: 2x the workgroups
         // one 8-wave workgroup per CU (256 slots): 128x192 unless its last round would be mostly idle
         const long tm = (a.M + 127) / 128;
