@@ -27,6 +27,15 @@ static int run128x192(const GemmArgs& a, hipStream_t s) { return launch16s_one<1
 // 4 waves, one per SIMD, 512 registers (wave tile 64 x 96)
 template <int EPI, int OUT, int DBG>
 static int run128x128(const GemmArgs& a, hipStream_t s) { return launch16s_one<128, 128, 4, 2, 3, EPI, OUT, 2, DBG>(a, s); }
+// the narrow tiles of small batches: one K tile per barrier on three stages, two per barrier on six
+template <int EPI, int OUT, int DBG>
+static int run128x32(const GemmArgs& a, hipStream_t s) { return launch16s_one<128, 32, 4, 1, 3, EPI, OUT, 2, DBG>(a, s); }
+template <int EPI, int OUT, int DBG>
+static int run128x32ks2(const GemmArgs& a, hipStream_t s) { return launch16s_one<128, 32, 4, 1, 6, EPI, OUT, 2, DBG, 2>(a, s); }
+template <int EPI, int OUT, int DBG>
+static int run64x32ks2(const GemmArgs& a, hipStream_t s) { return launch16s_one<64, 32, 2, 1, 6, EPI, OUT, 2, DBG, 2>(a, s); }
+template <int EPI, int OUT, int DBG>
+static int run64x64ks2(const GemmArgs& a, hipStream_t s) { return launch16s_one<64, 64, 2, 1, 6, EPI, OUT, 2, DBG, 2>(a, s); }
 template <int EPI, int OUT, int DBG>
 static int run4w(const GemmArgs& a, hipStream_t s) { return launch16s_one<128, 192, 2, 2, 3, EPI, OUT, 1, DBG>(a, s); }
 
@@ -58,6 +67,7 @@ int main(int argc, char** argv) {
         {"pwconv1 7680x2304x768 gelu->S32", 7680, 2304, 768, EPI_BIAS_GELU},
         {"pwconv2 7680x768x2304 gamma+res->f32", 7680, 768, 2304, EPI_BIAS_GAMMA_RES},
         {"head.out 7680x2432x768 exp/sincos->S32", 7680, 2432, 768, EPI_HEAD},
+        {"pwconv2 at B = 1: 120x768x2304 gamma+res->f32", 120, 768, 2304, EPI_BIAS_GAMMA_RES},
     };
     for (const Shape& sh : shapes) {
         std::vector<uint16_t> hA, hW;
@@ -110,6 +120,16 @@ int main(int argc, char** argv) {
                   {"no epilogue, DMA fetches nothing", run128x192<EPI_BIAS_GELU, OUT_S32, 4 + 131072>},
                   {"no epilogue, DMA re-reads one 8 KB window", run128x192<EPI_BIAS_GELU, OUT_S32, 4 + 1048576>},
                   {"no epilogue, no DMA", run128x192<EPI_BIAS_GELU, OUT_S32, 5>}};
+        } else if (sh.epi == EPI_BIAS_GAMMA_RES && sh.M < 1000) {
+            vs = {{"narrow 128x32, one K tile per barrier (r02)", run128x32<EPI_BIAS_GAMMA_RES, OUT_F32, 0>},
+                  {"narrow 128x32, two K tiles per barrier, six stages (shipped r03)", run128x32ks2<EPI_BIAS_GAMMA_RES, OUT_F32, 0>},
+                  {"64x32 tiles, 2 waves, two K tiles per barrier", run64x32ks2<EPI_BIAS_GAMMA_RES, OUT_F32, 0>},
+                  {"64x64 tiles, 2 waves, two K tiles per barrier", run64x64ks2<EPI_BIAS_GAMMA_RES, OUT_F32, 0>},
+                  {"narrow, one per barrier: no epilogue", run128x32<EPI_BIAS_GAMMA_RES, OUT_F32, 4>},
+                  {"narrow, one per barrier: no epilogue, DMA fetches nothing", run128x32<EPI_BIAS_GAMMA_RES, OUT_F32, 4 + 131072>},
+                  {"narrow, one per barrier: no epilogue, no DMA", run128x32<EPI_BIAS_GAMMA_RES, OUT_F32, 5>},
+                  {"narrow, one per barrier: no epilogue, no DMA, no barrier", run128x32<EPI_BIAS_GAMMA_RES, OUT_F32, 13>},
+                  {"narrow, one per barrier: no epilogue, no DMA, no barrier, no LDS reads", run128x32<EPI_BIAS_GAMMA_RES, OUT_F32, 29>}};
         } else if (sh.epi == EPI_HEAD) {
             // 8388608: direct (unstaged) 8-byte stores; 4194304: libm expf / sincosf; 128: no stores; 4: no epilogue
             vs = {{"r02: direct stores, libm expf/sincosf", run128x128<EPI_HEAD, OUT_S32, 4194304 + 8388608>},

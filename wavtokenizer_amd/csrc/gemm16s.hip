@@ -571,7 +571,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
     int rs = 0, ws = KS == 2 ? 4 : NSTAGE - 1;
     int c_par = 0;
     FragA Fa2;           // KS = 2: fragments of the second K tile of a pair
-    FragB F0b2;
+    FragB F0b2, F1b2;
     for (int vb = blockIdx.x; vb < ntiles; vb += G, c_par ^= 1) {
         // the table of this workgroup's next output tile: the loader turns to it NSTAGE-1 steps before this tile's
         // K loop ends, i.e. after at least one of the barriers below (host: nk >= NSTAGE + 1 in persistent launches)
@@ -608,20 +608,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
                 const int rs1 = rs + 1;                          // rs is even, < 6
                 load_tile(ws);
                 load_tile(ws + 1);
+                // every fragment of both tiles is requested before the first MFMA (both tiles have been visible since the last
+                // barrier): the LDS latency is paid once per pair, the MFMAs then run back to back
                 read_b16(rs, 1, F1b);
-                mfma16_block(Fa, F0b, std::integral_constant<int, 0>{}, [](int) {});
                 read_a16(rs1, Fa2);
                 read_b16(rs1, 0, F0b2);
+                read_b16(rs1, 1, F1b2);
+                mfma16_block(Fa, F0b, std::integral_constant<int, 0>{}, [](int) {});
                 mfma16_block(Fa, F1b, std::integral_constant<int, 1>{}, [](int) {});
-                read_b16(rs1, 1, F1b);
                 mfma16_block(Fa2, F0b2, std::integral_constant<int, 0>{}, [](int) {});
+                mfma16_block(Fa2, F1b2, std::integral_constant<int, 1>{}, [](int) {});
                 wait_vm_lgkm<2 * NPT>();     // all but the pair just requested; and this wave's LDS reads (their stages are the next DMA target)
                 __builtin_amdgcn_s_barrier();
                 rs = rs + 2 == 6 ? 0 : rs + 2;
                 ws = ws + 2 == 6 ? 0 : ws + 2;
-                read_a16(rs, Fa);            // first fragments of the next pair (after the last pair: of the next output tile)
-                read_b16(rs, 0, F0b);
-                mfma16_block(Fa2, F1b, std::integral_constant<int, 1>{}, [](int) {});
+                read_a16(rs, Fa);            // first fragments of the next pair (after the last pair: of the next output tile);
+                read_b16(rs, 0, F0b);        // their latency passes under the DMA issue at the top of the loop
             }
         } else
         for (int kt = 0; kt < nk; ++kt) {
