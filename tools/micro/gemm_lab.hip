@@ -33,6 +33,14 @@ static int run128x32(const GemmArgs& a, hipStream_t s) { return launch16s_one<12
 template <int EPI, int OUT, int DBG>
 static int run128x32ks2(const GemmArgs& a, hipStream_t s) { return launch16s_one<128, 32, 4, 1, 6, EPI, OUT, 2, DBG, 2>(a, s); }
 template <int EPI, int OUT, int DBG>
+static int run128x32prod(const GemmArgs& a, hipStream_t s) { return launch16s_one<128, 32, 4, 1, 6, EPI, OUT, 2, DBG, 2, 1>(a, s); }
+template <int EPI, int OUT, int DBG>
+static int run64x32prod(const GemmArgs& a, hipStream_t s) { return launch16s_one<64, 32, 2, 1, 6, EPI, OUT, 2, DBG, 2, 1>(a, s); }
+template <int EPI, int OUT, int DBG>
+static int run32x32prod(const GemmArgs& a, hipStream_t s) { return launch16s_one<32, 32, 1, 1, 6, EPI, OUT, 2, DBG, 2, 1>(a, s); }
+template <int EPI, int OUT, int DBG>
+static int run64x64prod(const GemmArgs& a, hipStream_t s) { return launch16s_one<64, 32, 2, 1, 6, EPI, OUT, 2, DBG, 2, 2>(a, s); }
+template <int EPI, int OUT, int DBG>
 static int run64x32ks2(const GemmArgs& a, hipStream_t s) { return launch16s_one<64, 32, 2, 1, 6, EPI, OUT, 2, DBG, 2>(a, s); }
 template <int EPI, int OUT, int DBG>
 static int run64x64ks2(const GemmArgs& a, hipStream_t s) { return launch16s_one<64, 64, 2, 1, 6, EPI, OUT, 2, DBG, 2>(a, s); }
@@ -123,6 +131,10 @@ int main(int argc, char** argv) {
         } else if (sh.epi == EPI_BIAS_GAMMA_RES && sh.M < 1000) {
             vs = {{"narrow 128x32, one K tile per barrier (r02)", run128x32<EPI_BIAS_GAMMA_RES, OUT_F32, 0>},
                   {"narrow 128x32, two K tiles per barrier, six stages (shipped r03)", run128x32ks2<EPI_BIAS_GAMMA_RES, OUT_F32, 0>},
+                  {"128x32, two K tiles per barrier + 4 loader waves", run128x32prod<EPI_BIAS_GAMMA_RES, OUT_F32, 0>},
+                  {"64x32, two K tiles per barrier + 2 loader waves", run64x32prod<EPI_BIAS_GAMMA_RES, OUT_F32, 0>},
+                  {"32x32, two K tiles per barrier + 1 loader wave", run32x32prod<EPI_BIAS_GAMMA_RES, OUT_F32, 0>},
+                  {"64x32, two K tiles per barrier + 4 loader waves", run64x64prod<EPI_BIAS_GAMMA_RES, OUT_F32, 0>},
                   {"64x32 tiles, 2 waves, two K tiles per barrier", run64x32ks2<EPI_BIAS_GAMMA_RES, OUT_F32, 0>},
                   {"64x64 tiles, 2 waves, two K tiles per barrier", run64x64ks2<EPI_BIAS_GAMMA_RES, OUT_F32, 0>},
                   {"narrow, one per barrier: no epilogue", run128x32<EPI_BIAS_GAMMA_RES, OUT_F32, 4>},

@@ -236,17 +236,26 @@ __device__ __forceinline__ void wait_vm_lgkm() {
 // fragment reads and MFMAs run back to back - such a launch is a chain of DMA-wait, barrier, LDS-read and MFMA latencies per
 // barrier, not of work (tools/step_times.py at B = 1), so half the barriers is most of the time.  Every accumulator still
 // sees its K tiles in ascending order: results are bit-identical to KS = 1
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int EPI, int OUT, int DBG = 0, int MF = WT_GEMM16S_MF, int WPS = 2, int KS = 1>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(const GemmArgs p) {
+// PROD = 1, 2 (with KS = 2): the workgroup carries PROD further sets of WAVES_M x WAVES_N waves that do nothing but the loader's
+// work (DMA issue and the wait for it, the pieces shared out among them); the first set does nothing but fragment reads,
+// MFMAs and the epilogue.  With one
+// wave per SIMD a wave pays for its DMA issue (5 pieces per K tile), its LDS reads and its MFMAs one after the other - at
+// B = 1 the sum IS the launch time (ladder in tools/micro/gemm_lab.hip: MFMA 7, LDS reads 4, barriers 3, DMA issue 5, data 8
+// of 35 us) - while two waves per SIMD with the roles split run the DMA side under the MFMA side
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int EPI, int OUT, int DBG = 0, int MF = WT_GEMM16S_MF, int WPS = 2, int KS = 1,
+          int PROD = 0>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * (1 + PROD), WPS) void gemm16s_kernel(const GemmArgs p) {
     constexpr int dbg = DBG;
     static_assert(KS == 1 || (KS == 2 && NSTAGE == 6 && MF == 1 && DBG == 0), "two K tiles per barrier: 6 stages (three pairs), 16x16x32 MFMA, no experiment masks");
-    constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
+    static_assert(!PROD || KS == 2, "loader waves: the two-tiles-per-barrier form only");
+    constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW * (1 + PROD);        // NW: MFMA waves
+    constexpr int NL = PROD ? NW * PROD : NW;                               // waves that issue the DMA pieces
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int STG = (BM + BN) * 128;                   // bytes per stage
-    constexpr int NPA = BM / 8 / NW, NPB = BN / 8 / NW;    // DMA pieces (8 rows x 128 B) per wave and K step
+    constexpr int NPA = BM / 8 / NL, NPB = BN / 8 / NL;    // DMA pieces (8 rows x 128 B) per loading wave and K step
     constexpr int NPT = NPA + NPB;
-    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "pieces must divide evenly among the waves");
+    static_assert(BM % (8 * NL) == 0 && BN % (8 * NL) == 0, "pieces must divide evenly among the loading waves");
     static_assert(WM % 32 == 0 && WN % 32 == 0 && BM % 16 == 0, "32x32 MFMA tiles");
     static_assert((NSTAGE - 2) * NPT < 64, "vmcnt field");
     extern __shared__ __attribute__((aligned(1024))) char smem_s[];
@@ -254,7 +263,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
     // the wave index as a SCALAR: with threadIdx.x >> 6 in a vector register every LDS-DMA destination (M0) went through
     // v_add + v_readfirstlane + s_mov per piece, and every per-wave offset cost vector instructions
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = (dbg & 65536) ? (tid >> 6) : __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = (dbg & 65536) ? (tid >> 6) : __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader_wave = PROD && wave_all >= NW;          // (scalar)
+    const bool mfma_wave = !loader_wave;
+    const bool dma_wave = !PROD || loader_wave;
+    const int wave = loader_wave ? wave_all - NW : wave_all;  // index within the role: a loader wave issues the pieces of its twin
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int ntiles = tiles_m * tiles_n;
@@ -346,13 +359,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
     unsigned a_chunk[NPA], w_chunk[NPB];
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
-        const int q = wave + NW * i;
+        const int q = wave + NL * i;
         a_row[i] = q * 8 + prow;
         a_chunk[i] = (unsigned)(((lane & 7) ^ (((q & 1) << 2) | (lane >> 4))) * 16);
     }
 #pragma unroll
     for (int j = 0; j < NPB; ++j) {
-        const int q = BM / 8 + wave + NW * j;
+        const int q = BM / 8 + wave + NL * j;
         w_chunk[j] = (unsigned)(((lane & 7) ^ (((q & 1) << 2) | (lane >> 4))) * 16);
     }
     unsigned a_voff[NPA], a2_voff[NPA], w_voff[NPB];
@@ -385,7 +398,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
         }
 #pragma unroll
         for (int j = 0; j < NPB; ++j) {
-            const int n = bn * BN + (wave + NW * j) * 8 + prow;
+            const int n = bn * BN + (wave + NL * j) * 8 + prow;
             w_voff[j] = n < p.N ? (unsigned)((long)n * p.w_rstride * 4) + w_chunk[j] : OOB;
         }
         set_tap(0);
@@ -398,19 +411,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
             // the K advance rides in the instruction's scalar offset (it is not part of the range check, which the
             // out-of-range marker in the vector offset still fails): no vector add per piece
             if (dbg & 1048576)      // timing experiment: real (non-zero) data, but always the same 8 KB: the cost of the traffic itself
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(sbase + NW * idx * 1024), 16, (int)(a_voff[idx] & 0x1fffu), 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(sbase + NL * idx * 1024), 16, (int)(a_voff[idx] & 0x1fffu), 0, 0, 0);
             else if (p.A2 && kL >= p.K1)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr_t)(sbase + NW * idx * 1024), 16,
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr_t)(sbase + NL * idx * 1024), 16,
                                                          (int)(a2_voff[idx] | l_mask), (kL - p.K1) * 4, 0, 0);
             else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(sbase + NW * idx * 1024), 16,
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(sbase + NL * idx * 1024), 16,
                                                          (int)(a_voff[idx] | l_mask), ciL * 4, 0, 0);
         } else {
             constexpr int j = idx - NPA;
             if (dbg & 1048576)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(sbase + (BM / 8 + NW * j) * 1024), 16, (int)(w_voff[j] & 0x1fffu), 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(sbase + (BM / 8 + NL * j) * 1024), 16, (int)(w_voff[j] & 0x1fffu), 0, 0, 0);
             else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(sbase + (BM / 8 + NW * j) * 1024), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(sbase + (BM / 8 + NL * j) * 1024), 16,
                                                      (int)(w_voff[j] | l_mask), kL * 4, 0, 0);
         }
     };
@@ -427,14 +440,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
         if (p.A2 && kL >= p.K1) {                                    // wave-uniform: this K tile comes from the second source
 #pragma unroll
             for (int i = 0; i < NPA; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr_t)(sbase + NW * i * 1024), 16, (int)(a2_voff[i] | l_mask), (kL - p.K1) * 4, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr_t)(sbase + NL * i * 1024), 16, (int)(a2_voff[i] | l_mask), (kL - p.K1) * 4, 0, 0);
         } else
 #pragma unroll
         for (int i = 0; i < NPA; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(sbase + NW * i * 1024), 16, (int)(a_voff[i] | l_mask), ciL * 4, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(sbase + NL * i * 1024), 16, (int)(a_voff[i] | l_mask), ciL * 4, 0, 0);
 #pragma unroll
         for (int j = 0; j < NPB; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(sbase + (BM / 8 + NW * j) * 1024), 16, (int)(w_voff[j] | l_mask), kL * 4, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(sbase + (BM / 8 + NL * j) * 1024), 16, (int)(w_voff[j] | l_mask), kL * 4, 0, 0);
         kL += SBK; ciL += SBK;
         if (kL >= p.K) {
             if (l_mask == 0) loader_set_tile(l_vb + G, l_par ^ 1);     // on into the next output tile
@@ -559,14 +572,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
     build_table(blockIdx.x, 0);
     __syncthreads();
     loader_set_tile(blockIdx.x, 0);
+    if (dma_wave) {
 #pragma unroll
-    for (int s = 0; s < (KS == 2 ? 4 : NSTAGE - 1); ++s) load_tile(s);       // needs nk >= NSTAGE - 1 when a next tile exists (host)
+        for (int s = 0; s < (KS == 2 ? 4 : NSTAGE - 1); ++s) load_tile(s);   // needs nk >= NSTAGE - 1 when a next tile exists (host)
+    }
     if (KS == 2) wait_vm_lgkm<2 * NPT>(); else wait_vm_lgkm<(NSTAGE - 2) * NPT>();
     __builtin_amdgcn_s_barrier();
     Frags F0, F1;
     FragA Fa;
     FragB F0b, F1b;
-    if (MF) { read_a16(0, Fa); read_b16(0, 0, F0b); }
+    if (MF) { if (mfma_wave) { read_a16(0, Fa); read_b16(0, 0, F0b); } }
     else read_frags(0, 0, F0);
     int rs = 0, ws = KS == 2 ? 4 : NSTAGE - 1;
     int c_par = 0;
@@ -582,7 +597,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
         // global load in the epilogue would have to wait for vmcnt(0), i.e. for every store issued before it, and the
         // epilogue would run one store round trip at a time (it did: 15 of pwconv1's 110 us).  The K loop's counted
         // waits only ever leave the youngest DMA pieces outstanding, so the cache is complete long before it is read.
-        if (PCACHE && lane < WN / 4) {
+        if (PCACHE && dma_wave && wave < NW && lane < WN / 4) {
             const int nb4 = (bn * BN + wn * WN + 4 * lane) * 4;
             char* pc = smem_s + p.pc_off + wave * PC_BYTES;
             if (p.bias) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBias, (lds_ptr_t)pc, 16, nb4, 0, 0, 0);
@@ -606,24 +621,30 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
             // iteration and is waited for at the bottom of this one; the pair after it is requested now.  nk is even (host)
             for (int kt = 0; kt < nk; kt += 2) {
                 const int rs1 = rs + 1;                          // rs is even, < 6
-                load_tile(ws);
-                load_tile(ws + 1);
-                // every fragment of both tiles is requested before the first MFMA (both tiles have been visible since the last
-                // barrier): the LDS latency is paid once per pair, the MFMAs then run back to back
-                read_b16(rs, 1, F1b);
-                read_a16(rs1, Fa2);
-                read_b16(rs1, 0, F0b2);
-                read_b16(rs1, 1, F1b2);
-                mfma16_block(Fa, F0b, std::integral_constant<int, 0>{}, [](int) {});
-                mfma16_block(Fa, F1b, std::integral_constant<int, 1>{}, [](int) {});
-                mfma16_block(Fa2, F0b2, std::integral_constant<int, 0>{}, [](int) {});
-                mfma16_block(Fa2, F1b2, std::integral_constant<int, 1>{}, [](int) {});
+                if (dma_wave) {
+                    load_tile(ws);
+                    load_tile(ws + 1);
+                }
+                if (mfma_wave) {
+                    // every fragment of both tiles is requested before the first MFMA (both tiles have been visible since the
+                    // last barrier): the LDS latency is paid once per pair, the MFMAs then run back to back
+                    read_b16(rs, 1, F1b);
+                    read_a16(rs1, Fa2);
+                    read_b16(rs1, 0, F0b2);
+                    read_b16(rs1, 1, F1b2);
+                    mfma16_block(Fa, F0b, std::integral_constant<int, 0>{}, [](int) {});
+                    mfma16_block(Fa, F1b, std::integral_constant<int, 1>{}, [](int) {});
+                    mfma16_block(Fa2, F0b2, std::integral_constant<int, 0>{}, [](int) {});
+                    mfma16_block(Fa2, F1b2, std::integral_constant<int, 1>{}, [](int) {});
+                }
                 wait_vm_lgkm<2 * NPT>();     // all but the pair just requested; and this wave's LDS reads (their stages are the next DMA target)
                 __builtin_amdgcn_s_barrier();
                 rs = rs + 2 == 6 ? 0 : rs + 2;
                 ws = ws + 2 == 6 ? 0 : ws + 2;
-                read_a16(rs, Fa);            // first fragments of the next pair (after the last pair: of the next output tile);
-                read_b16(rs, 0, F0b);        // their latency passes under the DMA issue at the top of the loop
+                if (mfma_wave) {
+                    read_a16(rs, Fa);        // first fragments of the next pair (after the last pair: of the next output tile);
+                    read_b16(rs, 0, F0b);    // their latency passes under the DMA issue at the top of the loop
+                }
             }
         } else
         for (int kt = 0; kt < nk; ++kt) {
@@ -713,6 +734,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WPS) void gemm16s_kernel(co
         }
 
     // ------------------------------------------------------------------------- epilogue
+    if (loader_wave) continue;               // (no barrier from here to the end of the tile loop)
     const int m_w = bm * BM + wm * WM, n_w = bn * BN + wn * WN;
     float* __restrict__ Cg = p.C + (long)z * p.zC;
     // sub-run s of a 32 x 32 block: its row and first column inside the block (see the accumulator layouts above)
@@ -1076,7 +1098,7 @@ int launch_pow2_scales(const float* a, long na, const float* b, long nb, unsigne
 }
 
 // ---------------------------------------------------------------------------------- host side
-template <int BM, int BN, int WMs, int WNs, int NSTAGE, int EPI, int OUT, int WPS = 2, int LABDBG = 0, int KS = 1>
+template <int BM, int BN, int WMs, int WNs, int NSTAGE, int EPI, int OUT, int WPS = 2, int LABDBG = 0, int KS = 1, int PROD = 0>
 static int launch16s_one(const GemmArgs& a, hipStream_t s) {
     if (KS == 2 && ((a.K / SBK) % 2 || a.K / SBK < 6)) { set_error("gemm16s: two K tiles per barrier need an even number (>= 6) of K tiles"); return -1; }
     static PerDeviceOnce attr_once;
@@ -1088,7 +1110,7 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
     static_assert(stage_bytes + 2 * BM * sizeof(unsigned) <= smem_cap, "LDS budget");
     if (smem > smem_cap) { set_error("gemm16s: too many taps for this tile's LDS budget"); return -1; }
     using kern_t = void (*)(const GemmArgs);
-    kern_t kern = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, LABDBG, WT_GEMM16S_MF, WPS, KS>;
+    kern_t kern = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, LABDBG, WT_GEMM16S_MF, WPS, KS, PROD>;
     // the timing-experiment builds exist for the tile the ConvNeXt GEMMs run on (tools/gemm16s_bench.py dbg): the masks of
     // the ablation ladder, each also with the clock stamps (+1024)
     constexpr bool has_dbg = LABDBG == 0 && KS == 1 && BM == 128 && BN == 192 && WMs == 4 && NSTAGE == 3 && ((EPI == EPI_BIAS && OUT == OUT_F32) || (EPI == EPI_BIAS_GELU && OUT == OUT_S32));
@@ -1112,7 +1134,7 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
         }
     }
     if (int rc = attr_once.run([&]() -> int {
-        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, LABDBG, WT_GEMM16S_MF, WPS, KS>),
+        WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, LABDBG, WT_GEMM16S_MF, WPS, KS, PROD>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max));
         for (int i = 0; i < 8; ++i)
             if (dbg_kerns[i]) WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dbg_kerns[i]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max));
@@ -1168,7 +1190,7 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
         b.stamp_start = g_launch.stamp_start; b.stamp_end = g_launch.stamp_end;
         g_launch.stamp_used = true;
     }
-    hipLaunchKernelGGL(kern, dim3(G, 1, a.nz), dim3(64 * WMs * WNs), smem, s, b);
+    hipLaunchKernelGGL(kern, dim3(G, 1, a.nz), dim3(64 * WMs * WNs * (1 + PROD)), smem, s, b);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1205,8 +1227,12 @@ static int launch16s_tiled(const GemmArgs& a, hipStream_t s) {
         const int nkt = a.K / SBK;
         const bool ks2 = ks2_env && nkt % 2 == 0 && nkt >= 6;
         // (with it a 128 x 32 tile walks K faster than a 128 x 64 tile does: it is used as long as all of its tiles run at once)
-        const long t32 = ((a.M + 127) / 128) * ((a.N + 31) / 32) * a.nz;
-        if (ks2 && t32 <= 256) return launch16s_one<128, 32, 4, 1, 6, EPI, OUT, 2, 0, 2>(a, s);
+        // ... and loader waves beside the MFMA waves (PROD).  Same-process ladder on pwconv2 at B = 1 (tools/micro/gemm_lab.hip):
+        // 128x32 one tile per barrier 35.6 us, two per barrier 32.2, + 4 loader waves 28-30; 64x32 + 2 loader waves 25, + 4: 23.7
+        const long cols32 = ((a.N + 31) / 32) * a.nz;
+        const long t32 = ((a.M + 127) / 128) * cols32, t64 = ((a.M + 63) / 64) * cols32;
+        if (ks2 && t64 <= 256) return launch16s_one<64, 32, 2, 1, 6, EPI, OUT, 2, 0, 2, 2>(a, s);
+        if (ks2 && t32 <= 256) return launch16s_one<128, 32, 4, 1, 6, EPI, OUT, 2, 0, 2, 1>(a, s);
         if (t128 <= 32) return launch16s_one<128, 32, 4, 1, 3, EPI, OUT>(a, s);
         if (t128 <= 100) return launch16s_one<128, 64, 4, 1, 3, EPI, OUT>(a, s);     // up to ~16 clips: 2x the workgroups
         // one 8-wave workgroup per CU (256 slots): 128x192 unless its last round would be mostly idle
