@@ -1206,6 +1206,12 @@ static int launch16s_tiled(const GemmArgs& a, hipStream_t s) {
     if constexpr (EPI == EPI_HEAD) {
         // wave tile 32 x 64: one whole 32-slot group per row block, staged full-line stores.  (7680 x 2432: 1140 tiles in 5
         // rounds of 232; 128 x 192 tiles need 4 rounds of 1.5 x the work each: 134 vs 127 us, tools/micro/gemm_lab.hip)
+        {   // a few clips: the small-problem form (below); its 32-column wave tile holds whole (log-mag, phase) pairs of 16 slots
+            static const bool ks2_env = [] { const char* e = getenv("WT_GEMM16S_KS"); return !e || e[0] != '1'; }();
+            const int nkt = a.K / SBK;
+            if (ks2_env && nkt % 2 == 0 && nkt >= 6 && ((a.M + 63) / 64) * ((a.N + 31) / 32) * a.nz <= 256)
+                return launch16s_one<64, 32, 2, 1, 6, EPI, OUT, 2, 0, 2, 2>(a, s);
+        }
         return launch16s_one<128, 128, 4, 2, 3, EPI, OUT>(a, s);
     } else if constexpr (EPI == EPI_ARGMAX) {
         return launch16s_one<128, 192, 4, 2, 3, EPI, OUT>(a, s);      // gemm16s_vq_parts() assumes this tile
