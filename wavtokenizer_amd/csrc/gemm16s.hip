@@ -1238,7 +1238,8 @@ static int launch16s_tiled(const GemmArgs& a, hipStream_t s) {
         const long cols32 = ((a.N + 31) / 32) * a.nz;
         const long t32 = ((a.M + 127) / 128) * cols32, t64 = ((a.M + 63) / 64) * cols32;
         if (ks2 && t64 <= 256) return launch16s_one<64, 32, 2, 1, 6, EPI, OUT, 2, 0, 2, 2>(a, s);
-        if (ks2 && t32 <= 256) return launch16s_one<128, 32, 4, 1, 6, EPI, OUT, 2, 0, 2, 1>(a, s);
+        if (ks2 && t32 <= 256 && a.nz == 1) return launch16s_one<128, 32, 4, 1, 6, EPI, OUT, 2, 0, 2, 1>(a, s);     // (batched per-clip
+                                                    // problems - the attention scores at B = 64 - are better off on 128x64: 21 vs 25 us)
         if (t128 <= 32) return launch16s_one<128, 32, 4, 1, 3, EPI, OUT>(a, s);
         if (t128 <= 100) return launch16s_one<128, 64, 4, 1, 3, EPI, OUT>(a, s);     // up to ~16 clips: 2x the workgroups
         // one 8-wave workgroup per CU (256 slots): 128x192 unless its last round would be mostly idle
