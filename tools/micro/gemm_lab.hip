@@ -41,6 +41,10 @@ static int run32x32prod(const GemmArgs& a, hipStream_t s) { return launch16s_one
 template <int EPI, int OUT, int DBG>
 static int run64x64prod(const GemmArgs& a, hipStream_t s) { return launch16s_one<64, 32, 2, 1, 6, EPI, OUT, 2, DBG, 2, 2>(a, s); }
 template <int EPI, int OUT, int DBG>
+static int run128x64(const GemmArgs& a, hipStream_t s) { return launch16s_one<128, 64, 4, 1, 3, EPI, OUT, 2, DBG>(a, s); }
+template <int EPI, int OUT, int DBG>
+static int run128x64prod(const GemmArgs& a, hipStream_t s) { return launch16s_one<128, 64, 4, 1, 6, EPI, OUT, 2, DBG, 2, 1>(a, s); }
+template <int EPI, int OUT, int DBG>
 static int run64x32ks2(const GemmArgs& a, hipStream_t s) { return launch16s_one<64, 32, 2, 1, 6, EPI, OUT, 2, DBG, 2>(a, s); }
 template <int EPI, int OUT, int DBG>
 static int run64x64ks2(const GemmArgs& a, hipStream_t s) { return launch16s_one<64, 64, 2, 1, 6, EPI, OUT, 2, DBG, 2>(a, s); }
@@ -76,6 +80,7 @@ int main(int argc, char** argv) {
         {"pwconv2 7680x768x2304 gamma+res->f32", 7680, 768, 2304, EPI_BIAS_GAMMA_RES},
         {"head.out 7680x2432x768 exp/sincos->S32", 7680, 2432, 768, EPI_HEAD},
         {"pwconv2 at B = 1: 120x768x2304 gamma+res->f32", 120, 768, 2304, EPI_BIAS_GAMMA_RES},
+        {"pwconv2 at B = 16: 1920x768x2304 gamma+res->f32", 1920, 768, 2304, EPI_BIAS_GAMMA_RES},
     };
     for (const Shape& sh : shapes) {
         std::vector<uint16_t> hA, hW;
@@ -128,6 +133,11 @@ int main(int argc, char** argv) {
                   {"no epilogue, DMA fetches nothing", run128x192<EPI_BIAS_GELU, OUT_S32, 4 + 131072>},
                   {"no epilogue, DMA re-reads one 8 KB window", run128x192<EPI_BIAS_GELU, OUT_S32, 4 + 1048576>},
                   {"no epilogue, no DMA", run128x192<EPI_BIAS_GELU, OUT_S32, 5>}};
+        } else if (sh.epi == EPI_BIAS_GAMMA_RES && sh.M == 1920) {
+            vs = {{"128x64, one K tile per barrier (shipped for 33-100 tiles of 128x128)", run128x64<EPI_BIAS_GAMMA_RES, OUT_F32, 0>},
+                  {"128x64, two K tiles per barrier + 4 loader waves", run128x64prod<EPI_BIAS_GAMMA_RES, OUT_F32, 0>},
+                  {"128x32, two K tiles per barrier + 4 loader waves (360 tiles)", run128x32prod<EPI_BIAS_GAMMA_RES, OUT_F32, 0>},
+                  {"128x128, 8 waves (the large-problem kernel)", run128x128<EPI_BIAS_GAMMA_RES, OUT_F32, 0>}};
         } else if (sh.epi == EPI_BIAS_GAMMA_RES && sh.M < 1000) {
             vs = {{"narrow 128x32, one K tile per barrier (r02)", run128x32<EPI_BIAS_GAMMA_RES, OUT_F32, 0>},
                   {"narrow 128x32, two K tiles per barrier, six stages (shipped r03)", run128x32ks2<EPI_BIAS_GAMMA_RES, OUT_F32, 0>},

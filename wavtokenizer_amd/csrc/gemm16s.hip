@@ -597,6 +597,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * (1 + PROD), WPS) void gemm
         // global load in the epilogue would have to wait for vmcnt(0), i.e. for every store issued before it, and the
         // epilogue would run one store round trip at a time (it did: 15 of pwconv1's 110 us).  The K loop's counted
         // waits only ever leave the youngest DMA pieces outstanding, so the cache is complete long before it is read.
+        // (loader waves skip the epilogue and would be here while the MFMA waves still read the previous tile's cache: in a
+        // persistent launch the two roles meet before it is overwritten)
+        if constexpr (PROD != 0 && PCACHE) { if (vb != (int)blockIdx.x) __syncthreads(); }
         if (PCACHE && dma_wave && wave < NW && lane < WN / 4) {
             const int nb4 = (bn * BN + wn * WN + 4 * lane) * 4;
             char* pc = smem_s + p.pc_off + wave * PC_BYTES;
@@ -1241,7 +1244,10 @@ static int launch16s_tiled(const GemmArgs& a, hipStream_t s) {
         if (ks2 && t32 <= 256 && a.nz == 1) return launch16s_one<128, 32, 4, 1, 6, EPI, OUT, 2, 0, 2, 1>(a, s);     // (batched per-clip
                                                     // problems - the attention scores at B = 64 - are better off on 128x64: 21 vs 25 us)
         if (t128 <= 32) return launch16s_one<128, 32, 4, 1, 3, EPI, OUT>(a, s);
-        if (t128 <= 100) return launch16s_one<128, 64, 4, 1, 3, EPI, OUT>(a, s);     // up to ~16 clips: 2x the workgroups
+        if (t128 <= 100) {     // up to ~16 clips: 2x the workgroups; with loader waves where six stages fit beside the offset tables
+            if (ks2 && a.nz == 1 && a.taps <= 7 && !a.A2) return launch16s_one<128, 64, 4, 1, 6, EPI, OUT, 2, 0, 2, 1>(a, s);
+            return launch16s_one<128, 64, 4, 1, 3, EPI, OUT>(a, s);
+        }
         // one 8-wave workgroup per CU (256 slots): 128x192 unless its last round would be mostly idle
         const long tm = (a.M + 127) / 128;
         auto cost = [&](int bn, double eff) {
