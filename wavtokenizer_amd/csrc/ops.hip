@@ -792,7 +792,12 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
     const float* Co = parts + Mrows * Kq;
     const float* Se = parts + 2 * Mrows * Kq;
     const float* So = parts + 3 * Mrows * Kq;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    // Workgroup i runs on XCD i % 8 and every spectrum value is read by four output samples up to n_fft apart: with the
+    // chunks of 256 samples dealt out round robin each XCD's L2 fetched (nearly) all of `parts` for itself (301 MB of traffic
+    // for 93 MB, profiles/r03_pmc_traffic.json).  XCD x takes the x-th contiguous eighth of the chunks instead
+    const long nchunk = (long)gridDim.x;                     // a multiple of 8 (host), one chunk per workgroup
+    const long chunk = (long)(blockIdx.x & 7) * (nchunk >> 3) + (blockIdx.x >> 3);
+    for (long idx = chunk * blockDim.x + threadIdx.x; idx < total; idx += total) {       // (one pass)
         const long b = idx / Tout;
         const long u = idx - b * Tout;
         const long up = u + pad;
@@ -822,8 +827,9 @@ int launch_istft_ola(const float* parts, const float* win, const float* wsq, flo
     const long Tout = center ? (long)hop * (L - 1) : (long)hop * L;
     const long total = (long)B * Tout;
     if (total <= 0) return 0;
-    int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(istft_ola_kernel, dim3(blocks), dim3(256), 0, s, parts, win, wsq, out, total, (long)B * L, L, n_fft,
+    const long blocks = (((total + 255) / 256) + 7) / 8 * 8;          // one 256-sample chunk per workgroup, a multiple of 8
+    if (blocks > 0x7fffffffL) { set_error("istft_ola: too many samples for one launch"); return -1; }
+    hipLaunchKernelGGL(istft_ola_kernel, dim3((unsigned)blocks), dim3(256), 0, s, parts, win, wsq, out, total, (long)B * L, L, n_fft,
                        hop, Kq, pad, Tout);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
