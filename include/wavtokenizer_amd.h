@@ -103,8 +103,24 @@ enum {
                                       launches as a hipGraph, later calls with those buffers replay it (one
                                       hipGraphLaunch on the caller's stream); any other call launches directly.  Such a
                                       plan must not be run from two host threads at once */
-    WT_PLAN_FLAG_FP32_GEMM = 2     /* every dense layer on the fp32 MFMA chain; default: the fp32-equivalent
+    WT_PLAN_FLAG_FP32_GEMM = 2,    /* every dense layer on the fp32 MFMA chain; default: the fp32-equivalent
                                       split-f16 kernel (3 f16 MFMAs per product, fp32 accumulate) where covered */
+    WT_PLAN_FLAG_RANGE_REPORT = 32 /* diagnostic: behind every step, the largest magnitude held by each S32 (split-f16) buffer the
+                                      step touches is measured (wt_plan_range_report): the head-room of every dense layer's
+                                      operands below the f16 limit 65504.  Costs a pass per buffer; never graph-replayed */
+};
+
+/* Range sites: the units in which a plan can leave the split-f16 form on its own (wt_plan_create_ex, wt_plan_range_sites).
+ * Every S32 tensor is produced and consumed inside one site.  Bit i of a site mask = site i. */
+enum wt_range_site {
+    WT_SITE_ENCODER = 0,       /* the whole encode plan: SEANetEncoder + VQ (encoder/modules/seanet.py:66-144) */
+    WT_SITE_BB_EMBED = 1,      /* backbone.embed (decoder/models.py:177) */
+    WT_SITE_RES0 = 2, WT_SITE_RES1 = 3,   /* pos_net ResnetBlocks (decoder/models.py:19-78) */
+    WT_SITE_ATTN = 4,          /* AttnBlock (decoder/models.py:80-127) */
+    WT_SITE_RES2 = 5, WT_SITE_RES3 = 6,
+    WT_SITE_CNX0 = 7,          /* ConvNeXtBlock i = WT_SITE_CNX0 + i (decoder/modules.py:8-60), i < 32 */
+    WT_SITE_HEAD = 40,         /* final_layer_norm output + ISTFTHead (decoder/heads.py:24-67) */
+    WT_SITE_SEANET_DECODER = 41
 };
 
 const char* wt_last_error(void);
@@ -134,11 +150,21 @@ int  wt_packed_verify(const void* buf, size_t n);
 size_t wt_packed_bytes(const void* buf, size_t n);
 int  wt_model_create_packed(const void* buf, size_t n, int32_t device, wt_model** out);
 int  wt_model_hop(const wt_model* m);                 /* prod(ratios) */
+/* 1 while the model's plans may launch the persistent LSTM kernel (a 256-CU device and no lost-co-residency report so far) */
+int  wt_model_persistent_lstm(const wt_model* m);
+/* What the library sees of a device: compute units, whether it is gfx950 (wt_model_create refuses anything else), whether
+ * the persistent LSTM can run there (256 CUs = 8 XCDs x 32; a compute partition runs the launch-per-step kernel and sizes
+ * every persistent launch by its own CU count). */
+int  wt_device_info(int32_t device, int32_t* compute_units, int32_t* is_gfx950, int32_t* persistent_lstm);
 int64_t wt_model_weight_bytes(const wt_model* m);     /* packed fp32 bytes resident in HBM */
 
 /* A plan fixes (kind, B, T or L): kernel launch list + workspace layout.
  * `len` = T (samples) for WT_PLAN_ENCODE, L (frames) for the two decode kinds. */
 int    wt_plan_create(const wt_model* m, int32_t kind, int32_t B, int64_t len, int32_t flags, wt_plan** out);
+/* ... with a mask of range sites (wt_range_site) that keep fp32 operands and run their GEMMs on the fp32 MFMA chain while
+ * every other site stays on the split-f16 kernel: the answer to WT_ERR_RANGE that costs one block, not the model. */
+int    wt_plan_create_ex(const wt_model* m, int32_t kind, int32_t B, int64_t len, int32_t flags, uint64_t fp32_sites,
+                         wt_plan** out);
 void   wt_plan_destroy(wt_plan* p);
 size_t wt_plan_workspace_bytes(const wt_plan* p);
 int64_t wt_plan_frames(const wt_plan* p);             /* L = ceil(T / hop) (conv.py:54-61) */
@@ -156,6 +182,13 @@ int    wt_plan_buffer_info(const wt_plan* p, const char* name, size_t* offset, s
  * WT_STATUS_BIT_LSTM); bits left unconsumed make the next wt_encode / wt_decode / ... return WT_ERR_LSTM_SYNC /
  * WT_ERR_RANGE once. */
 int    wt_plan_status(const wt_plan* p, int32_t* bits, int32_t clear);
+/* Which range sites of this plan reported WT_STATUS_BIT_RANGE since the last clear (a site downstream of the first one
+ * that overflowed usually reports too: infinities propagate; put the LOWEST set site on fp32 and run again). */
+int    wt_plan_range_sites(const wt_plan* p, uint64_t* sites, int32_t clear);
+/* WT_PLAN_FLAG_RANGE_REPORT plans, after a call: entry `index` of the report = (step name, S32 buffer name, largest
+ * magnitude found in that buffer right behind that step; +inf if a value left the f16 range).  Synchronises the device on the
+ * first query after a call.  Returns WT_ERR_INVALID past the last entry. */
+int    wt_plan_range_report(const wt_plan* p, int32_t index, const char** step, const char** buffer, float* amax);
 /* The same bits collected over ALL plans of the model (each plan's guard step reports into this word too, and it
  * outlives plans that were destroyed): what the next call on any plan of the model will consume. */
 int    wt_model_status(const wt_model* m, int32_t* bits, int32_t clear);

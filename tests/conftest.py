@@ -19,8 +19,9 @@ def pytest_sessionstart(session):
     """The HIP library is git-ignored (built in-tree): build it if a fresh checkout has none, so the C-ABI
     export test and the GPU tests never run against a missing or silently absent extension."""
     lib = os.path.join(ROOT, "wavtokenizer_amd", "libwavtok_hip.so")
-    if not os.path.exists(lib):
-        subprocess.run(["make", "-C", os.path.join(ROOT, "wavtokenizer_amd", "csrc"), "-j4"], check=True)
+    lab = os.path.join(ROOT, "tools", "lib", "libwavtok_hip_lab.so")
+    if not os.path.exists(lib) or not os.path.exists(lab):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "wavtokenizer_amd", "csrc"), "-j8", "all", "lab"], check=True)
 
 
 @pytest.fixture(scope="session")

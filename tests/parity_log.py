@@ -17,7 +17,7 @@ def dump():
         return None
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    path = os.path.join(out_dir, "gpu_parity_summary.json")
+    path = os.path.join(out_dir, os.environ.get("WAVTOK_PARITY_SUMMARY", "gpu_parity_summary.json"))
     with open(path, "w") as f:
         json.dump(RECORDS, f, indent=1, sort_keys=True, default=str)
     flips = sum(int(v.get("code_flips", 0)) for v in RECORDS.values())

@@ -457,3 +457,112 @@ def test_step_runner_lanes_are_single_rank_only():
         StepRunner(object(), wav, torch.tensor([0]), object(), 2, 0, gather=True, backend="gloo", lanes=2)
     r = StepRunner(object(), wav, torch.tensor([0]), None, 1, 0, gather=True, lanes=1)      # world 1: no exchange, one lane
     assert r.lanes == 1 and r.streams is None and not r.gather
+
+
+def test_product_library_reads_no_environment_and_carries_no_lab_kernels():
+    """the product library must not reach getenv from any launch path and must not carry the
+    timing-experiment kernel builds or the LSTM fault hook.  Every environment switch of csrc/ goes through lab_env(), a
+    constant in the product build (common.h): no object of the product build references getenv at all; the LAB build
+    (make lab -> tools/lib/libwavtok_hip_lab.so, what tools/*.py and tests/lab load through WAVTOK_HIP_LIB) does."""
+    import glob
+    import subprocess
+    csrc = os.path.join(ROOT, "wavtokenizer_amd", "csrc")
+    objs = sorted(glob.glob(os.path.join(csrc, "build", "*.o")))
+    assert len(objs) >= 10, objs
+    for o in objs:
+        undefined = subprocess.run(["nm", "-u", o], capture_output=True, text=True, check=True).stdout
+        assert "getenv" not in undefined, o
+    src = "".join(open(f).read() for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.cpp")))
+    assert "getenv(" not in src                                  # only common.h's lab_env (LAB builds) calls it
+    dyn = subprocess.run(["nm", "-D", os.path.join(ROOT, "wavtokenizer_amd", "libwavtok_hip.so")], capture_output=True, text=True, check=True).stdout
+    assert " U getenv" not in dyn
+    # no experiment instantiations among the product's kernels: gemm16s_kernel<..., DBG, ...> has DBG == 0 everywhere, the
+    # resblock16 ablation builds (<..., true, ...>) and the LSTM phase-trace builds (<..., true>) are absent
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    names = list(kr.kernel_table())
+    for n in names:
+        m = re.search(r"gemm16s_kernel<(.*?)>", n)
+        if m:
+            args = [a.strip() for a in m.group(1).split(",")]
+            assert args[7] == "0", n                             # template argument DBG
+        m = re.search(r"resblock16_kernel<(.*?)>", n)
+        if m:
+            assert m.group(1).split(",")[3].strip() == "false", n
+        m = re.search(r"lstm_persist_kernel<(.*?)>", n)
+        if m:
+            assert m.group(1).split(",")[1].strip() == "false", n
+    assert not os.path.exists(os.path.join(ROOT, "wavtokenizer_amd", "libwavtok_hip_prev.so"))
+    lab = os.path.join(ROOT, "tools", "lib", "libwavtok_hip_lab.so")
+    if os.path.exists(lab):
+        lab_dyn = subprocess.run(["nm", "-D", lab], capture_output=True, text=True, check=True).stdout
+        assert " U getenv" in lab_dyn
+        lab_names = list(kr.kernel_table(lab))
+        assert len(lab_names) > len(names)
+
+
+def test_check_codes_mode_defaults_to_sync_and_is_validated(monkeypatch):
+    """codes_to_features must raise for the offending call by default (F.embedding does:
+    decoder/pretrained.py:236); 'deferred' is opt-in, '1' means sync, unknown values are refused."""
+    from wavtokenizer_amd import WavTokenizer, ARCH_HOP600
+    monkeypatch.delenv("WAVTOK_CHECK_CODES", raising=False)
+    assert WavTokenizer.from_arch(ARCH_HOP600)._check_codes == "sync"
+    monkeypatch.setenv("WAVTOK_CHECK_CODES", "1")
+    assert WavTokenizer.from_arch(ARCH_HOP600)._check_codes == "sync"
+    monkeypatch.setenv("WAVTOK_CHECK_CODES", "deferred")
+    assert WavTokenizer.from_arch(ARCH_HOP600)._check_codes == "deferred"
+    monkeypatch.setenv("WAVTOK_CHECK_CODES", "0")
+    assert WavTokenizer.from_arch(ARCH_HOP600)._check_codes == "off"
+    monkeypatch.setenv("WAVTOK_CHECK_CODES", "later")
+    with pytest.raises(ValueError, match="WAVTOK_CHECK_CODES"):
+        WavTokenizer.from_arch(ARCH_HOP600)
+
+
+def test_strict_status_is_automatic_for_small_batches():
+    """VERDICT r03 #3c: calls of up to the graph batch limit synchronise, check and repeat a failed call (an infer.py-style
+    caller never receives poisoned tensors); larger batches stay asynchronous; both can be forced."""
+    from wavtokenizer_amd import WavTokenizer, ARCH_HOP600
+    m = WavTokenizer.from_arch(ARCH_HOP600)
+    assert m._is_strict(1) and m._is_strict(16) and not m._is_strict(17) and not m._is_strict(64)
+    m.set_graph_max_clips(0)
+    assert not m._is_strict(1)
+    m.set_strict_status(True)
+    assert m._is_strict(64)
+    m.set_strict_status(False)
+    assert not m._is_strict(1)
+    m.set_strict_status(None)
+    m.set_graph_max_clips(16)
+    assert m._is_strict(4)
+
+
+def test_range_sites_select_per_plan_kind():
+    """An overflow answered in one ConvNeXt block must not re-plan the encoder (the site mask a plan kind sees)."""
+    from wavtokenizer_amd import WavTokenizer, ARCH_HOP600, _capi
+    from wavtokenizer_amd.pretrained import site_name
+    m = WavTokenizer.from_arch(ARCH_HOP600)
+    m._fp32_sites = (1 << (_capi.WT_SITE_CNX0 + 5)) | (1 << _capi.WT_SITE_HEAD)
+    assert m._sites(_capi.WT_PLAN_ENCODE) == 0
+    assert m._sites(_capi.WT_PLAN_DECODE) == m._fp32_sites
+    assert m._sites(_capi.WT_PLAN_HEAD) == 1 << _capi.WT_SITE_HEAD
+    m._fp32_sites |= 1 << _capi.WT_SITE_ENCODER
+    assert m._sites(_capi.WT_PLAN_ENCODE) == 1 and not (m._sites(_capi.WT_PLAN_DECODE) & 1)
+    assert site_name(_capi.WT_SITE_CNX0 + 5) == "backbone.convnext.5" and "head" in site_name(_capi.WT_SITE_HEAD)
+
+
+def test_plan_cache_bounds_streams():
+    """plans are per stream; a caller that uses a new stream per request must not fill the cache with plans of
+    streams it never uses again (host logic of _Engine, no GPU: keys only)."""
+    from wavtokenizer_amd.pretrained import _Engine
+    e = _Engine()
+    e.max_streams = 2
+    dropped = []
+    e.drop = lambda pred: dropped.append([k for k in list(e.plans) if pred(k)]) or [e.plans.pop(k) for k in list(e.plans) if pred(k)]
+    for sp in (11, 22, 33):
+        e.plans[(0, 1, 100, 0, sp)] = (None, None)
+        e._touch_stream(sp)
+    assert e.stream_lru == [22, 33] and (0, 1, 100, 0, 11) not in e.plans and (0, 1, 100, 0, 33) in e.plans
+    e._touch_stream(22)
+    assert e.stream_lru == [33, 22]
+    e.plans.clear()

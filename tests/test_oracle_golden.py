@@ -56,6 +56,20 @@ def test_non_multiple_of_hop(oracle):
     assert rel_l2(wav.numpy(), g["wav_out"]) < FLOAT_TOL
 
 
+def test_inputs_outside_the_synth_family(oracle):
+    """Silence, -70 / -110 dBFS, full-scale square, impulse, DC, x30, hard-clipped: the fixture written from the reference
+    (tests/golden/make_golden_inputs.py, which also asserted that the float64 run picks the same codes)."""
+    name, orc = oracle
+    g = load_case(name, "inputs")
+    assert g["codes_equal_float64"].all() and float(g["margin"].min()) >= 0.02
+    with torch.inference_mode():
+        feats, codes = orc.encode_infer(torch.from_numpy(g["wav_in"]), BW)
+        wav = orc.decode(feats, BW).numpy()
+    assert check_codes(codes.numpy(), g["codes"], g["margin"], name) == 0
+    for i, nm in enumerate(g["names"]):
+        assert rel_l2(wav[i], g["wav_out"][i]) < FLOAT_TOL, str(nm)
+
+
 def test_edge_lengths(oracle):
     name, orc = oracle
     g = load_case(name, "edge")

@@ -64,7 +64,7 @@ if __name__ == "__main__":
         sys.exit(0)
     r = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     masks = [int(m) for m in sys.argv[2:]] or [0]
-    prev = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "wavtokenizer_amd", "libwavtok_hip_prev.so")
+    prev = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "lib", "libwavtok_hip_prev.so")
     for m in masks:                      # the mask is read once per process: one child per mask
         env = dict(os.environ, WT_RB16_DBG=str(m))
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", str(r)], env=env, capture_output=True, text=True)

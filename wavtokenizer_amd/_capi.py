@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("WAVTOK_HIP_LIB") or os.path.join(_HERE, "libwavtok_hi
 EXPORTS = [
     "wt_last_error", "wt_version", "wt_model_create", "wt_model_destroy", "wt_model_export_bytes", "wt_model_export", "wt_packed_info", "wt_packed_verify", "wt_packed_bytes",
     "wt_model_create_packed", "wt_model_hop", "wt_model_weight_bytes",
-    "wt_plan_create", "wt_plan_destroy", "wt_plan_workspace_bytes", "wt_plan_frames", "wt_plan_num_launches", "wt_plan_graph_replays",
+    "wt_plan_create", "wt_plan_create_ex", "wt_plan_range_sites", "wt_plan_range_report", "wt_model_persistent_lstm", "wt_device_info", "wt_plan_destroy", "wt_plan_workspace_bytes", "wt_plan_frames", "wt_plan_num_launches", "wt_plan_graph_replays",
     "wt_plan_find_buffer", "wt_plan_buffer_info", "wt_plan_buffer_name", "wt_plan_status", "wt_plan_num_steps", "wt_plan_step_name",
     "wt_plan_set_timing", "wt_plan_read_timing", "wt_model_split_ok", "wt_model_status", "wt_model_take_bad_codes", "wt_encode", "wt_codes_to_features",
     "wt_decode", "wt_seanet_decode", "wt_head", "wt_unit_run", "wt_sconv1d", "wt_linear", "wt_conv1d_s32", "wt_vq_workspace_bytes",
@@ -32,6 +32,9 @@ WT_PLAN_FLAG_FP32_GEMM = 2
 WT_PLAN_FLAG_STEP_LSTM = 4
 WT_PLAN_FLAG_GRAPH = 8
 WT_PLAN_FLAG_UNFUSED = 16
+WT_PLAN_FLAG_RANGE_REPORT = 32
+WT_SITE_ENCODER, WT_SITE_BB_EMBED, WT_SITE_RES0, WT_SITE_RES1, WT_SITE_ATTN, WT_SITE_RES2, WT_SITE_RES3 = 0, 1, 2, 3, 4, 5, 6
+WT_SITE_CNX0, WT_SITE_HEAD, WT_SITE_SEANET_DECODER = 7, 40, 41
 WT_ERR_RANGE, WT_ERR_LSTM_SYNC, WT_ERR_INDEX = -6, -7, -8
 WT_STATUS_BIT_LSTM, WT_STATUS_BIT_RANGE = 1, 2
 BUF_S32, BUF_ELU = 1, 2
@@ -91,6 +94,11 @@ def _load() -> ctypes.CDLL:
     lib.wt_model_weight_bytes.argtypes = [c_void_p]
     lib.wt_model_weight_bytes.restype = c_int64
     lib.wt_plan_create.argtypes = [c_void_p, c_int32, c_int32, c_int64, c_int32, POINTER(c_void_p)]
+    lib.wt_plan_create_ex.argtypes = [c_void_p, c_int32, c_int32, c_int64, c_int32, ctypes.c_uint64, POINTER(c_void_p)]
+    lib.wt_plan_range_sites.argtypes = [c_void_p, POINTER(ctypes.c_uint64), c_int32]
+    lib.wt_plan_range_report.argtypes = [c_void_p, c_int32, POINTER(c_char_p), POINTER(c_char_p), POINTER(c_float)]
+    lib.wt_model_persistent_lstm.argtypes = [c_void_p]
+    lib.wt_device_info.argtypes = [c_int32, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]
     lib.wt_plan_destroy.argtypes = [c_void_p]
     lib.wt_plan_destroy.restype = None
     lib.wt_plan_workspace_bytes.argtypes = [c_void_p]

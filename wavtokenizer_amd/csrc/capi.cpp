@@ -5,6 +5,18 @@ namespace wt {
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
 thread_local LaunchCtx g_launch;
+int device_cus() {
+    static std::atomic<int> cache[64];
+    int d = 0;
+    (void)hipGetDevice(&d);
+    d &= 63;
+    int v = cache[d].load(std::memory_order_relaxed);
+    if (v <= 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || v <= 0) v = 256;
+        cache[d].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
 }  // namespace wt
 
 // ================================================================================== C ABI
@@ -27,10 +39,28 @@ static int alloc_host_words(wt_model* M, const char* who) {
     return WT_OK;
 }
 
+// The library holds gfx950 code objects only.  Launch geometry follows the device's CU count (device_cus()); what is tied to
+// the full 256-CU / 8-XCD MI355X is the persistent LSTM (plan.cpp: any other CU count runs the launch-per-step kernel) and
+// the tuning of the tile orders (speed only).  A device of another architecture is refused here instead of at the first launch.
+static int check_device(int device, const char* who) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); set_error(std::string(who) + ": no such device"); return WT_ERR_HIP; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error(std::string(who) + ": device is " + prop.gcnArchName + "; this library is built for gfx950 (MI355X) only");
+        return WT_ERR_INVALID;
+    }
+    if (prop.multiProcessorCount < 8) { set_error(std::string(who) + ": fewer than 8 compute units"); return WT_ERR_INVALID; }
+    return WT_OK;
+}
+
 extern "C" {
 
 const char* wt_last_error(void) { return g_err.c_str(); }
+#ifdef WT_LAB
+const char* wt_version(void) { return "wavtokenizer_amd 0.1 LAB build (gfx950, split-f16 MFMA products, fp32 accumulation; timing experiments and fault hooks compiled in)"; }
+#else
 const char* wt_version(void) { return "wavtokenizer_amd 0.1 (gfx950, split-f16 MFMA products, fp32 accumulation)"; }
+#endif
 
 int wt_model_create(const wt_arch* arch, const wt_tensor* tensors, int32_t n_tensors, int32_t device, wt_model** out) {
     if (!arch || !tensors || !out) { set_error("wt_model_create: null argument"); return WT_ERR_INVALID; }
@@ -41,6 +71,7 @@ int wt_model_create(const wt_arch* arch, const wt_tensor* tensors, int32_t n_ten
     if (arch->dim % 32 || (arch->dim / 32) % 4) { set_error("dim/32 (GroupNorm group width) must be a multiple of 4"); return WT_ERR_INVALID; }
     DeviceGuard dg(device);
     if (!dg.ok) { set_error("wt_model_create: hipSetDevice failed"); return WT_ERR_HIP; }
+    if (int rc = check_device(device, "wt_model_create")) return rc;
     std::unique_ptr<wt_model> M(new wt_model());
     M->arch = *arch;
     M->device = device;
@@ -81,6 +112,7 @@ int wt_model_create_packed(const void* buf, size_t n, int32_t device, wt_model**
     if (int rc = packed_info(buf, n, nullptr, nullptr, nullptr)) return rc;
     DeviceGuard dg(device);
     if (!dg.ok) { set_error("wt_model_create_packed: hipSetDevice failed"); return WT_ERR_HIP; }
+    if (int rc = check_device(device, "wt_model_create_packed")) return rc;
     std::unique_ptr<wt_model> M(new wt_model());
     M->device = device;
     int rc;
@@ -116,11 +148,29 @@ int wt_model_status(const wt_model* m, int32_t* bits, int32_t clear) {
     if (bits) *bits = (int32_t)b;
     return WT_OK;
 }
+int wt_model_persistent_lstm(const wt_model* m) {
+    if (!m || !m->persist_ok.load()) return 0;
+    int cus = 0;
+    return hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device) == hipSuccess && cus == 256 ? 1 : 0;
+}
+int wt_device_info(int32_t device, int32_t* compute_units, int32_t* is_gfx950, int32_t* persistent_lstm) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); set_error("wt_device_info: no such device"); return WT_ERR_HIP; }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (is_gfx950) *is_gfx950 = strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+    if (persistent_lstm) *persistent_lstm = prop.multiProcessorCount == 256 ? 1 : 0;
+    return WT_OK;
+}
 int wt_model_hop(const wt_model* m) { return m ? m->hop : 0; }
 int64_t wt_model_weight_bytes(const wt_model* m) { return m ? m->weight_bytes : 0; }
 
 int wt_plan_create(const wt_model* m, int32_t kind, int32_t B, int64_t len, int32_t flags, wt_plan** out) {
+    return wt_plan_create_ex(m, kind, B, len, flags, 0, out);
+}
+
+int wt_plan_create_ex(const wt_model* m, int32_t kind, int32_t B, int64_t len, int32_t flags, uint64_t fp32_sites, wt_plan** out) {
     if (!m || !out) { set_error("wt_plan_create: null argument"); return WT_ERR_INVALID; }
+    if (m->arch.num_layers > SITE_HEAD - SITE_CNX0) { set_error("wt_plan_create: more ConvNeXt blocks than range sites"); return WT_ERR_INVALID; }
     if (B < 1 || len < 1) { set_error("wt_plan_create: B and len must be >= 1"); return WT_ERR_INVALID; }
     if ((len + (kind == WT_PLAN_ENCODE ? m->hop - 1 : 0)) / (kind == WT_PLAN_ENCODE ? m->hop : 1) > 12000) {
         set_error("clips longer than 12000 frames are not supported by one plan; split the clip"); return WT_ERR_INVALID;
@@ -128,7 +178,7 @@ int wt_plan_create(const wt_model* m, int32_t kind, int32_t B, int64_t len, int3
     DeviceGuard dg(m->device);
     if (!dg.ok) { set_error("wt_plan_create: hipSetDevice failed"); return WT_ERR_HIP; }
     std::unique_ptr<wt_plan> P(new wt_plan());
-    P->model = m; P->kind = kind; P->B = B; P->len = len; P->flags = flags;
+    P->model = m; P->kind = kind; P->B = B; P->len = len; P->flags = flags; P->fp32_sites = fp32_sites;
     {
         void* hp = nullptr;
         void* dp = nullptr;
@@ -136,12 +186,12 @@ int wt_plan_create(const wt_model* m, int32_t kind, int32_t B, int64_t len, int3
             if (hp) (void)hipHostFree(hp);
             set_error("wt_plan_create: no host-mapped memory for the status word"); return WT_ERR_HIP;
         }
-        P->status_host = static_cast<unsigned*>(hp);
+        P->status_host = static_cast<unsigned*>(hp);       // word 0: status bits; words 2, 3: mask of the range sites that reported
         P->status_dev = static_cast<unsigned*>(dp);
-        *P->status_host = 0;
+        memset(hp, 0, 64);
     }
     // a model that came from a packed image holds no fp32 copies of its GEMM weights until a plan needs them
-    if (m->f32_stale.load() && ((flags & (WT_PLAN_FLAG_FP32_GEMM | WT_PLAN_FLAG_UNFUSED)) || !m->s32_ok ||
+    if (m->f32_stale.load() && ((flags & (WT_PLAN_FLAG_FP32_GEMM | WT_PLAN_FLAG_UNFUSED)) || fp32_sites || !m->s32_ok ||
                                 (kind == WT_PLAN_SEANET_DECODER && !m->sd_s32_ok)))
         if (int rc0 = ensure_f32_weights(m)) return rc0;
     plan_begin(P.get());
@@ -171,6 +221,12 @@ int wt_plan_create(const wt_model* m, int32_t kind, int32_t B, int64_t len, int3
     if (rc) return rc;              // ~wt_plan releases the host-mapped word
     plan_end(P.get());
     P->layout();
+    if (!P->range_entries.empty()) {
+        if (hipMalloc(reinterpret_cast<void**>(&P->range_dev), (P->range_entries.size() * sizeof(unsigned) + 15) / 16 * 16) != hipSuccess) {
+            P->range_dev = nullptr; set_error("wt_plan_create: no memory for the range report"); return WT_ERR_HIP;
+        }
+        P->range_host.assign(P->range_entries.size(), 0.f);
+    }
     *out = P.release();
     return WT_OK;
 }
@@ -307,7 +363,7 @@ static int run_plan(const wt_plan* p, const RunCtx& c) {
 
 static int run_plan_locked(const wt_plan* p, const RunCtx& c) {
     const bool timing = !p->timing_filter.empty();
-    if ((p->flags & WT_PLAN_FLAG_GRAPH) && !timing && !p->graph_failed) {
+    if ((p->flags & WT_PLAN_FLAG_GRAPH) && !timing && !p->graph_failed && !p->range_dev) {
         const wt_plan::GraphKey key{c.ws, c.in_f, c.out_f, c.codes, c.aux, c.bw_id};
         if (p->graph_exec && key == p->graph_key) {
             WT_HIP_CHECK(hipGraphLaunch(p->graph_exec, c.stream));
@@ -323,7 +379,11 @@ static int run_plan_locked(const wt_plan* p, const RunCtx& c) {
             cc.stream = p->cap_stream;
             WT_HIP_CHECK(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeRelaxed));
             int rc = WT_OK;
-            for (size_t i = 0; i < p->steps.size() && !rc; ++i) rc = p->steps[i](cc);
+            unsigned* const cap_base = reinterpret_cast<unsigned*>(cc.ws + p->bufs[p->ctl].off);
+            for (size_t i = 0; i < p->steps.size() && !rc; ++i) {
+                g_launch.status = cap_base + CTL_SITE0 + p->step_sites[i];
+                rc = p->steps[i](cc);
+            }
             hipGraph_t g = nullptr;
             const hipError_t ce = hipStreamEndCapture(p->cap_stream, &g);
             if (rc || ce != hipSuccess || !g) {
@@ -337,7 +397,10 @@ static int run_plan_locked(const wt_plan* p, const RunCtx& c) {
                 if (ie != hipSuccess) { p->graph_exec = nullptr; p->graph_failed = true; (void)hipGetLastError(); }
                 else {
                     p->graph_key = key;
-                    p->graph_persist = p->uses_persist;       // recorded while wt_model::persist_ok held (checked on entry)
+                    // the recording holds a persistent launch only if the model still allowed one when it was made: after a
+                    // lost-co-residency fallback the steps record the launch-per-step kernel, and such a graph must survive
+                    // consume_status (it used to be destroyed and re-captured on every other call for the rest of the model's life)
+                    p->graph_persist = p->uses_persist && p->model->persist_ok.load();
                     WT_HIP_CHECK(hipGraphLaunch(p->graph_exec, c.stream));
                     ++p->graph_replays;
                     return WT_OK;
@@ -352,7 +415,23 @@ static int run_plan_locked(const wt_plan* p, const RunCtx& c) {
     // start / stop events behave the same: 95.1 vs 90.3)
     const bool stamp = timing && p->timing_filter[0] == '@';
     const std::string filt = stamp ? p->timing_filter.substr(1) : p->timing_filter;
+    unsigned* const ctl_base = reinterpret_cast<unsigned*>(c.ws + p->bufs[p->ctl].off);
+    size_t next_range = 0;
+    if (p->range_dev) {
+        if (int rc = launch_fill_u32(p->range_dev, 0u, (p->range_entries.size() * sizeof(unsigned) + 15) / 16 * 16, c.stream)) return rc;
+        p->range_fresh = false;
+    }
+    // WT_PLAN_FLAG_RANGE_REPORT: behind step i, the largest magnitude in every S32 buffer the step touches
+    auto measure_ranges = [&](size_t i) -> int {
+        for (; next_range < p->range_entries.size() && p->range_entries[next_range].step == (int)i; ++next_range) {
+            const BufSpec& b = p->bufs[p->range_entries[next_range].buf];
+            if (int rc = launch_s32_amax(c.ws + b.off, (long)b.numel, p->range_dev + next_range, c.stream)) return rc;
+        }
+        return 0;
+    };
     for (size_t i = 0; i < p->steps.size(); ++i) {
+        // the step's kernels report into their site's word of the control block (model.h Site)
+        g_launch.status = ctl_base + CTL_SITE0 + p->step_sites[i];
         const bool timed = timing && p->step_names[i].find(filt) != std::string::npos;
         std::pair<hipEvent_t, hipEvent_t> ev;
         if (timed && stamp) {
@@ -362,6 +441,7 @@ static int run_plan_locked(const wt_plan* p, const RunCtx& c) {
                 g_launch.stamp_used = false;
             }
             const int step_rc = p->steps[i](c);
+            if (!step_rc) if (int rc = measure_ranges(i)) return rc;
             const bool armed = g_launch.stamp_start != nullptr, used = g_launch.stamp_used;
             g_launch.stamp_start = g_launch.stamp_end = nullptr; g_launch.stamp_used = false;
             if (step_rc) return step_rc;
@@ -379,7 +459,8 @@ static int run_plan_locked(const wt_plan* p, const RunCtx& c) {
         }
         const int step_rc = p->steps[i](c);
         if (int rc = step_rc) return rc;
-        static const bool dbg_status = getenv("WT_DEBUG_STATUS") != nullptr;
+        if (int rc = measure_ranges(i)) return rc;
+        const bool dbg_status = lab_env("WT_DEBUG_STATUS") != nullptr;      // LAB builds only
         if (dbg_status) {        // debugging aid: which step left a non-zero status word (synchronises after every step)
             unsigned st = 0;
             WT_HIP_CHECK(hipStreamSynchronize(c.stream));
@@ -406,6 +487,37 @@ int wt_plan_status(const wt_plan* p, int32_t* bits, int32_t clear) {
         b = p->status_host ? __atomic_load_n(p->status_host, __ATOMIC_ACQUIRE) : 0u;
     }
     if (bits) *bits = (int32_t)b;
+    return WT_OK;
+}
+
+int wt_plan_range_sites(const wt_plan* p, uint64_t* sites, int32_t clear) {
+    if (!p || !sites) return WT_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(p->mu);
+    unsigned lo = 0, hi = 0;
+    if (p->status_host) {
+        lo = clear ? __atomic_exchange_n(p->status_host + 2, 0u, __ATOMIC_ACQUIRE) : __atomic_load_n(p->status_host + 2, __ATOMIC_ACQUIRE);
+        hi = clear ? __atomic_exchange_n(p->status_host + 3, 0u, __ATOMIC_ACQUIRE) : __atomic_load_n(p->status_host + 3, __ATOMIC_ACQUIRE);
+    }
+    *sites = ((uint64_t)hi << 32) | lo;
+    return WT_OK;
+}
+
+int wt_plan_range_report(const wt_plan* p, int32_t index, const char** step, const char** buffer, float* amax) {
+    if (!p) return WT_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(p->mu);
+    if (!p->range_dev) { set_error("wt_plan_range_report: the plan was not created with WT_PLAN_FLAG_RANGE_REPORT"); return WT_ERR_INVALID; }
+    if (index < 0 || index >= (int)p->range_entries.size()) return WT_ERR_INVALID;       // past the end (no message: callers iterate)
+    if (!p->range_fresh) {
+        DeviceGuard dg(p->model->device);
+        WT_HIP_CHECK(hipDeviceSynchronize());
+        static_assert(sizeof(float) == sizeof(unsigned), "bit patterns");
+        WT_HIP_CHECK(hipMemcpy(p->range_host.data(), p->range_dev, p->range_entries.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+        p->range_fresh = true;
+    }
+    const wt_plan::RangeEntry& e = p->range_entries[index];
+    if (step) *step = p->step_names[e.step].c_str();
+    if (buffer) *buffer = p->bufs[e.buf].name.c_str();
+    if (amax) *amax = p->range_host[index];
     return WT_OK;
 }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <mutex>
 #include <string>
 
@@ -55,6 +56,21 @@ struct LaunchCtx {
     bool stamp_used = false;
 };
 extern thread_local LaunchCtx g_launch;
+
+// Compute units of the current device (cached per device).  Launch geometry is derived from it: the persistent GEMM and
+// resblock launches run one (or two) workgroups per CU of THIS device; only the persistent LSTM is tied to the full
+// 256-CU / 8-XCD MI355X (plan.cpp) and falls back to the launch-per-step kernel anywhere else (a CPX / NPS partition).
+int device_cus();
+
+// Environment switches.  The PRODUCT library reads none on any launch path: lab_env() is a constant there, so the sweeps,
+// A/B switches and fault hooks below cost nothing and cannot be reached (tests/test_host_logic.py checks that no object of
+// the product build references getenv).  A LAB build (make LAB=1: -DWT_LAB, tools/lib/libwavtok_hip_lab.so, what tools/*.py,
+// tools/micro/gemm_lab.hip and the fault-injection tests load through WAVTOK_HIP_LIB) reads them per call.
+#ifdef WT_LAB
+inline const char* lab_env(const char* name) { return getenv(name); }
+#else
+inline const char* lab_env(const char*) { return nullptr; }
+#endif
 
 #if defined(__HIPCC__)
 // largest |v| of a value that is being converted to the split-f16 form; NaNs are ignored (they propagate by themselves)
@@ -233,8 +249,10 @@ int launch_codes_to_features(const int64_t* codes, const float* embed, int K, in
 // buffer fill as a kernel (hipMemsetAsync nodes misbehave under hipGraph replay: ops.hip); 16-byte aligned pointer and size
 int launch_fill_u32(void* p, unsigned value, size_t n_bytes, hipStream_t s);
 // last step of every plan: on a non-zero status word poison the outputs (codes = -1, floats = NaN) and publish the bits
-int launch_plan_guard(const unsigned* status, unsigned* host_status, unsigned* model_status, int64_t* codes, long n_codes,
-                      float* f0, long n0, float* f1, long n1, float* f2, long n2, hipStream_t s);
+int launch_plan_guard(const unsigned* status, int nwords, int site0, unsigned* host_status, unsigned* model_status, int64_t* codes,
+                      long n_codes, float* f0, long n0, float* f1, long n1, float* f2, long n2, hipStream_t s);
+// max |value| of an S32 array as the bit pattern of a float, atomicMax-ed into *out_bits (range report)
+int launch_s32_amax(const void* s32, long numel, unsigned* out_bits, hipStream_t s);
 struct LstmArgs {
     const float* xg0;     // [L][B][4H] (time-major) layer-0 input projection (+ both biases), packed gate order
     const float* W0;      // W_hh_l0, per 16 packed gate rows: [H/16][64 lanes][4] (ops.hip lstm_step_kernel)

@@ -342,9 +342,8 @@ static int launch_one(const GemmArgs& a, hipStream_t s) {
 
 // experiment hook (tools/gemm_bench.py): WT_GEMM_TILE picks another tile for plain bias GEMMs
 static int tile_override() {
-    static int v = -2;
-    if (v == -2) { const char* e = getenv("WT_GEMM_TILE"); v = e ? atoi(e) : -1; }
-    return v;
+    const char* e = lab_env("WT_GEMM_TILE");       // LAB builds only
+    return e ? atoi(e) : -1;
 }
 
 template <int PRO, int EPI>
@@ -385,9 +384,7 @@ int gemm_vq_parts(int N) { return ((N + 127) / 128) * 2; }
 
 // row-tiles per scheduling group (see the tile remap in the kernel)
 static int pick_group_m(const GemmArgs& a) {
-    static int env = -2;
-    if (env == -2) { const char* e = getenv("WT_GEMM_GM"); env = e ? atoi(e) : -1; }
-    if (env > 0) return env;
+    if (const char* e = lab_env("WT_GEMM_GM")) if (atoi(e) > 0) return atoi(e);      // LAB builds only (tools/gm_sweep.sh)
     // An XCD runs ~64 tiles at once and its 4 MiB L2 only holds what they stream in lockstep, so
     // fabric reads ~ sum over such waves of (distinct A panels + distinct W panels).  With many column
     // tiles an 8 x 8 wave is the minimum; with <= 8 column tiles a full row of tiles already is one

@@ -1114,11 +1114,12 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
     if (smem > smem_cap) { set_error("gemm16s: too many taps for this tile's LDS budget"); return -1; }
     using kern_t = void (*)(const GemmArgs);
     kern_t kern = gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, LABDBG, WT_GEMM16S_MF, WPS, KS, PROD>;
-    // the timing-experiment builds exist for the tile the ConvNeXt GEMMs run on (tools/gemm16s_bench.py dbg): the masks of
-    // the ablation ladder, each also with the clock stamps (+1024)
+#ifdef WT_LAB
+    // LAB builds only: the timing-experiment builds of the tile the ConvNeXt GEMMs run on (tools/gemm16s_bench.py dbg): the
+    // masks of the ablation ladder, each with the clock stamps (+1024), selected by WT_GEMM16S_DBG per launch
     constexpr bool has_dbg = LABDBG == 0 && KS == 1 && BM == 128 && BN == 192 && WMs == 4 && NSTAGE == 3 && ((EPI == EPI_BIAS && OUT == OUT_F32) || (EPI == EPI_BIAS_GELU && OUT == OUT_S32));
     int dbg_req = 0;
-    if (const char* e = getenv("WT_GEMM16S_DBG")) dbg_req = atoi(e);
+    if (const char* e = lab_env("WT_GEMM16S_DBG")) dbg_req = atoi(e);
     kern_t dbg_kerns[8] = {};
     static constexpr int dbg_masks[8] = {1024, 1024 + 4, 1024 + 5, 1024 + 13, 1024 + 45, 1024 + 61, 1024 + 64, 1024 + 21};
     if constexpr (has_dbg) {
@@ -1136,11 +1137,14 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
             if (!kern) { set_error("gemm16s: no timing-experiment build for this WT_GEMM16S_DBG mask"); return -1; }
         }
     }
+#endif
     if (int rc = attr_once.run([&]() -> int {
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm16s_kernel<BM, BN, WMs, WNs, NSTAGE, EPI, OUT, LABDBG, WT_GEMM16S_MF, WPS, KS, PROD>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max));
+#ifdef WT_LAB
         for (int i = 0; i < 8; ++i)
             if (dbg_kerns[i]) WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dbg_kerns[i]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max));
+#endif
         return 0;
     })) return rc;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
@@ -1149,13 +1153,14 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
     // b, b + G, ... with its loader streaming across the seams.  The slot count must stay a multiple of 8 so that a
     // workgroup's tiles stay on its XCD, and K must be deep enough for the table hand-over (see the kernel).
     const int per_cu = (WPS >= 2 && WMs * WNs <= 4 && smem * 2 <= smem_cap) ? 2 : 1;
-    int G = (256 * per_cu / a.nz) & ~7;
-    const char* np = getenv("WT_GEMM16S_NONPERSISTENT");
+    const int ncu = device_cus();
+    int G = (ncu * per_cu / a.nz) & ~7;
+    const char* np = lab_env("WT_GEMM16S_NONPERSISTENT");
     if (G < 8 || ntiles <= G || a.K / SBK < NSTAGE + 1 || (np && np[0] == '1')) G = ntiles;
     else {
         // the same number of rounds with the fewest workgroups (720 tiles: 240 x 3 instead of 208 x 3 + 48 x 2): the idle
         // CUs' power goes to the clock of the busy ones
-        static const bool bal = [] { const char* e = getenv("WT_GEMM16S_BALANCE"); return !e || e[0] != '0'; }();
+        const bool bal = [] { const char* e = lab_env("WT_GEMM16S_BALANCE"); return !e || e[0] != '0'; }();
         const int rounds = (ntiles + G - 1) / G;
         const int g2 = (((ntiles + rounds - 1) / rounds) + 7) & ~7;
         if (bal && g2 < G) G = g2;
@@ -1179,7 +1184,7 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
                                    (OUT == OUT_S32 && (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ELU)) ||
                                    (OUT == OUT_S32 && EPI == EPI_HEAD && (BN / WNs) % 64 == 0);
         const size_t off = (smem + 127) / 128 * 128;
-        const char* ns = getenv("WT_GEMM16S_NOSTAGE");
+        const char* ns = lab_env("WT_GEMM16S_NOSTAGE");
         constexpr bool dual = OUT == OUT_S32_DUAL_ELU || OUT == OUT_F32_AND_S32;
         if (can_stage && off + (size_t)WMs * WNs * 4096 <= smem_cap && a.N % (EPI == EPI_HEAD ? 64 : 32) == 0 &&
             !(EPI == EPI_HEAD && (a.head_kb % 32 || a.c_rstride % 32)) && !(ns && ns[0] == '1') &&
@@ -1200,7 +1205,7 @@ static int launch16s_one(const GemmArgs& a, hipStream_t s) {
 
 #ifndef WT_GEMM16S_LAB      // tools/micro/gemm_lab.hip includes this file and instantiates the variants it compares itself
 static int tile16s_override() {
-    const char* e = getenv("WT_GEMM16S_TILE");      // read per launch: tools/gemm16s_bench.py switches it in-process
+    const char* e = lab_env("WT_GEMM16S_TILE");      // LAB builds: read per launch, tools/gemm16s_bench.py switches it in-process
     return e ? atoi(e) : -1;
 }
 
@@ -1210,9 +1215,9 @@ static int launch16s_tiled(const GemmArgs& a, hipStream_t s) {
         // wave tile 32 x 64: one whole 32-slot group per row block, staged full-line stores.  (7680 x 2432: 1140 tiles in 5
         // rounds of 232; 128 x 192 tiles need 4 rounds of 1.5 x the work each: 134 vs 127 us, tools/micro/gemm_lab.hip)
         {   // a few clips: the small-problem form (below); its 32-column wave tile holds whole (log-mag, phase) pairs of 16 slots
-            static const bool ks2_env = [] { const char* e = getenv("WT_GEMM16S_KS"); return !e || e[0] != '1'; }();
+            const bool ks2_env = [] { const char* e = lab_env("WT_GEMM16S_KS"); return !e || e[0] != '1'; }();
             const int nkt = a.K / SBK;
-            if (ks2_env && nkt % 2 == 0 && nkt >= 6 && ((a.M + 63) / 64) * ((a.N + 31) / 32) * a.nz <= 256)
+            if (ks2_env && nkt % 2 == 0 && nkt >= 6 && ((a.M + 63) / 64) * ((a.N + 31) / 32) * a.nz <= device_cus())
                 return launch16s_one<64, 32, 2, 1, 6, EPI, OUT, 2, 0, 2, 2>(a, s);
         }
         return launch16s_one<128, 128, 4, 2, 3, EPI, OUT>(a, s);
@@ -1232,7 +1237,7 @@ static int launch16s_tiled(const GemmArgs& a, hipStream_t s) {
         // K step).  Every tile shape accumulates K in the same order: results do not depend on the choice
         const long t128 = ((a.M + 127) / 128) * ((a.N + 127) / 128) * a.nz;
         // ... and two K tiles per barrier where K allows (KS = 2: these launches are latency chains, see the kernel)
-        static const bool ks2_env = [] { const char* e = getenv("WT_GEMM16S_KS"); return !e || e[0] != '1'; }();
+        const bool ks2_env = [] { const char* e = lab_env("WT_GEMM16S_KS"); return !e || e[0] != '1'; }();
         const int nkt = a.K / SBK;
         const bool ks2 = ks2_env && nkt % 2 == 0 && nkt >= 6;
         // (with it a 128 x 32 tile walks K faster than a 128 x 64 tile does: it is used as long as all of its tiles run at once)
@@ -1240,8 +1245,9 @@ static int launch16s_tiled(const GemmArgs& a, hipStream_t s) {
         // 128x32 one tile per barrier 35.6 us, two per barrier 32.2, + 4 loader waves 28-30; 64x32 + 2 loader waves 25, + 4: 23.7
         const long cols32 = ((a.N + 31) / 32) * a.nz;
         const long t32 = ((a.M + 127) / 128) * cols32, t64 = ((a.M + 63) / 64) * cols32;
-        if (ks2 && t64 <= 256) return launch16s_one<64, 32, 2, 1, 6, EPI, OUT, 2, 0, 2, 2>(a, s);
-        if (ks2 && t32 <= 256 && a.nz == 1) return launch16s_one<128, 32, 4, 1, 6, EPI, OUT, 2, 0, 2, 1>(a, s);     // (batched per-clip
+        const int ncu = device_cus();
+        if (ks2 && t64 <= ncu) return launch16s_one<64, 32, 2, 1, 6, EPI, OUT, 2, 0, 2, 2>(a, s);
+        if (ks2 && t32 <= ncu && a.nz == 1) return launch16s_one<128, 32, 4, 1, 6, EPI, OUT, 2, 0, 2, 1>(a, s);     // (batched per-clip
                                                     // problems - the attention scores at B = 64 - are better off on 128x64: 21 vs 25 us)
         if (t128 <= 32) return launch16s_one<128, 32, 4, 1, 3, EPI, OUT>(a, s);
         if (t128 <= 100) {     // up to ~16 clips: 2x the workgroups; with loader waves where six stages fit beside the offset tables
@@ -1252,7 +1258,7 @@ static int launch16s_tiled(const GemmArgs& a, hipStream_t s) {
         const long tm = (a.M + 127) / 128;
         auto cost = [&](int bn, double eff) {
             const long t = tm * ((a.N + bn - 1) / bn) * a.nz;
-            return std::ceil((double)t / 256.0) * bn / eff;
+            return std::ceil((double)t / (double)ncu) * bn / eff;
         };
         if (cost(128, 0.82) < cost(192, 1.0)) return launch16s_one<128, 128, 4, 2, 3, EPI, OUT>(a, s);
         return launch16s_one<128, 192, 4, 2, 3, EPI, OUT>(a, s);
@@ -1300,8 +1306,8 @@ int launch_gemm16s(const GemmArgs& a_in, int epi, int out, hipStream_t s) {
     const int tiles_n192 = (a.N + 191) / 192;
     a.group_m = tiles_n192 > 8 ? 8 : 1;
     if (tiles_n192 >= 12 && tiles_n192 % 6 == 0 && a.nz == 1) { a.group_m = 5; a.group_n = 6; }
-    if (const char* e = getenv("WT_GEMM16S_GM")) { a.group_m = atoi(e) > 0 ? atoi(e) : a.group_m; a.group_n = 0; }      // sweeps (tools/gemm16s_bench.py)
-    if (const char* e = getenv("WT_GEMM16S_GN")) a.group_n = atoi(e);
+    if (const char* e = lab_env("WT_GEMM16S_GM")) { a.group_m = atoi(e) > 0 ? atoi(e) : a.group_m; a.group_n = 0; }      // sweeps (tools/gemm16s_bench.py)
+    if (const char* e = lab_env("WT_GEMM16S_GN")) a.group_n = atoi(e);
     if ((out == OUT_S32_DUAL_ELU || out == OUT_F32_AND_S32) && !c.C2) { set_error("gemm16s: this output format needs C2"); return -1; }
     if (epi == EPI_HEAD && (!c.bias || c.N % 32 || c.head_kb <= 0)) { set_error("gemm16s: head epilogue needs a bias, N % 32 == 0 and head_kb"); return -1; }
     if (epi == EPI_ARGMAX && (!c.vq_xx || !c.vq_ee || !c.vq_pval || !c.vq_pidx || c.vq_nparts != gemm16s_vq_parts(c.N))) {

@@ -330,25 +330,31 @@ int launch_lstm_persist(const LstmPersistArgs& a, hipStream_t stream) {
     if (int rc = attr_once.run([&]() -> int {
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_big));
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_small));
+#ifdef WT_LAB
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_big));
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_small));
+#endif
         return 0;
     })) return rc;
     // the caller has filled hx and ctl with 0xFF bytes (the marks of the data-flag exchange)
     const bool small = a.Bx <= 8;
     LstmPersistArgs b = a;
     if (!b.status) b.status = g_launch.status;
-    // Test hook (tests/test_gpu_parity.py::test_persistent_lstm_lost_coresidency): WT_LSTM_PERSIST_FAULT=1 launches 8
-    // workgroups too few, so every XCD waits for a 32nd workgroup that never comes, and shortens the spin bounds; the
-    // kernel must then report WT_STATUS_LSTM instead of handing out a half-written sequence
-    const char* fault = getenv("WT_LSTM_PERSIST_FAULT");
+    // Fault injection, LAB builds only (tests/lab/test_lab_faults.py, run on tools/lib/libwavtok_hip_lab.so): WT_LSTM_PERSIST_FAULT=1
+    // launches 8 workgroups too few, so every XCD waits for a 32nd workgroup that never comes, and shortens the spin bounds;
+    // the kernel must then report WT_STATUS_LSTM instead of handing out a half-written sequence.  The product library has
+    // neither the hook nor the phase-timestamp instantiations (tools/lstm_trace.py)
+    const char* fault = lab_env("WT_LSTM_PERSIST_FAULT");
     const bool forced = fault && fault[0] == '1';
     if (forced) b.dbg_spin_shift = 8;
     const dim3 grid(forced ? 248 : 256), block(64 * PW);
+#ifdef WT_LAB
     if (a.data_flag & 4) {          // phase timestamps (tools/lstm_trace.py)
         if (small) hipLaunchKernelGGL((lstm_persist_kernel<true, true>), grid, block, smem_small, stream, b);
         else hipLaunchKernelGGL((lstm_persist_kernel<false, true>), grid, block, smem_big, stream, b);
-    } else {
+    } else
+#endif
+    {
         if (small) hipLaunchKernelGGL((lstm_persist_kernel<true>), grid, block, smem_small, stream, b);
         else hipLaunchKernelGGL((lstm_persist_kernel<false>), grid, block, smem_big, stream, b);
     }

@@ -149,6 +149,23 @@ struct RunCtx {
     float* aux;              // emb_out (encode) / backbone_out (decode)
     int bw_id;
 };
+// Range sites (wt_plan_create_ex, wt_plan_range_sites): the units in which a plan can leave the split-f16 (S32) form.  Every
+// S32 tensor is produced and consumed inside ONE site, so a site can run on fp32 operands (gemm.hip) on its own while the
+// rest of the plan stays on gemm16s.hip: an activation beyond the f16 range in one ConvNeXt block costs that block's two
+// GEMMs on the fp32 pipe, not the whole model.  The steps of a site report WT_STATUS_RANGE into the
+// site's own word of the call's control block (ctl[CTL_SITE0 + site]); the guard step publishes the mask of sites that did.
+enum Site : int {
+    SITE_ENC = 0,            // the whole encode plan (and WT_PLAN_UNIT_LSTM)
+    SITE_BB_EMBED = 1,       // transpose + backbone.embed
+    SITE_RES0 = 2, SITE_RES1 = 3, SITE_ATTN = 4, SITE_RES2 = 5, SITE_RES3 = 6,
+    SITE_CNX0 = 7,           // ConvNeXt block i: SITE_CNX0 + i (num_layers <= 32)
+    SITE_HEAD = 40,          // final LayerNorm output + ISTFT head (also the WT_PLAN_HEAD plan)
+    SITE_SEADEC = 41,        // the SEANetDecoder plan
+    SITE_COUNT = 64
+};
+constexpr int CTL_SITE0 = 16;                 // first site word of the control block
+constexpr int CTL_WORDS = CTL_SITE0 + SITE_COUNT + 48;      // 128 words = 512 bytes
+
 // what a stage buffer holds (wt_plan_buffer_info): fp32 values, or the S32 split-f16 encoding of them; and whether
 // the values are the reference tensor's or elu() of it (producers apply ELU once where the only consumer is ELU -> conv)
 enum BufFmt : int { BUF_F32 = 0, BUF_S32 = 1, BUF_ELU = 2 };
@@ -176,9 +193,18 @@ struct wt_plan {
     const wt_model* model = nullptr;
     int kind = 0, B = 0, flags = 0;
     int64_t len = 0, L = 0, T = 0;
+    uint64_t fp32_sites = 0;              // sites (wt::Site) that run on fp32 operands (wt_plan_create_ex)
+    int cur_site = 0;                     // site of the steps being added (plan.cpp)
     std::vector<wt::BufSpec> bufs;
     std::vector<std::function<int(const wt::RunCtx&)>> steps;
     std::vector<std::string> step_names;
+    std::vector<int> step_sites;          // site of every step: its kernels report WT_STATUS_RANGE into ctl[CTL_SITE0 + site]
+    // WT_PLAN_FLAG_RANGE_REPORT: after every step, the largest magnitude in each S32 buffer the step touches (capi.cpp)
+    struct RangeEntry { int step, buf; };
+    std::vector<RangeEntry> range_entries;
+    unsigned* range_dev = nullptr;        // one word (fp32 bit pattern of the maximum) per entry
+    mutable std::vector<float> range_host;
+    mutable bool range_fresh = false;
     size_t ws_bytes = 0;
     int n_launches = 0;
     // optional HIP-event timing of the steps whose name contains `timing_filter` (bench.py roofline
@@ -220,6 +246,7 @@ struct wt_plan {
     wt_plan(const wt_plan&) = delete;
     ~wt_plan() {
         if (status_host) (void)hipHostFree(status_host);
+        if (range_dev) (void)hipFree(range_dev);
         if (stamps) (void)hipFree(stamps);
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
@@ -243,8 +270,12 @@ struct wt_plan {
             bufs[id].last = std::max(bufs[id].last, s);
             if (name.empty()) nm = bufs[id].name;      // default: the last buffer the step touches
         }
+        if (flags & WT_PLAN_FLAG_RANGE_REPORT)
+            for (int id : used)
+                if (id >= 0 && (bufs[id].fmt & wt::BUF_S32)) range_entries.push_back({s, id});
         steps.push_back(std::move(fn));
         step_names.push_back(nm);
+        step_sites.push_back(cur_site);
         n_launches += launches;
     }
     float* ptr(const wt::RunCtx& c, int id) const { return reinterpret_cast<float*>(c.ws + bufs[id].off); }

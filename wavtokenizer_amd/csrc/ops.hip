@@ -840,14 +840,34 @@ int launch_istft_ola(const float* parts, const float* win, const float* wsq, flo
 // (common.h: WT_STATUS_*) the call's outputs are overwritten — codes with -1, float outputs with NaN — so that a
 // failed call can never hand out plausible-looking data, and the bits are OR-ed into the plan's host-visible word,
 // where the next host call on the plan (or wt_plan_status) finds them.
-__global__ __launch_bounds__(256) void plan_guard_kernel(const unsigned* __restrict__ status, unsigned* host_status,
+// The control block holds `nwords` status words: word 0 (plan-level reports) and, from word `site0` on, one word per range
+// site (model.h Site: the steps of a site report into the site's word).  Their OR is the call's status; the sites whose word
+// carries WT_STATUS_RANGE are published as a 64-bit mask in host_status[2..3], so the host can put exactly those sites on
+// fp32 operands instead of the whole model.
+__global__ __launch_bounds__(256) void plan_guard_kernel(const unsigned* __restrict__ status, int nwords, int site0, unsigned* host_status,
                                                          unsigned* model_status, int64_t* codes, long n_codes, float* f0, long n0, float* f1, long n1,
                                                          float* f2, long n2) {
-    const unsigned st = *status;
+    __shared__ unsigned s_or, s_lo, s_hi;
+    if (threadIdx.x == 0) { s_or = 0u; s_lo = 0u; s_hi = 0u; }
+    __syncthreads();
+    if ((int)threadIdx.x < nwords) {
+        const unsigned w = status[threadIdx.x];
+        if (w) {
+            atomicOr(&s_or, w);
+            const int site = (int)threadIdx.x - site0;
+            if ((w & WT_STATUS_RANGE) && site >= 0 && site < 64) atomicOr(site < 32 ? &s_lo : &s_hi, 1u << (site & 31));
+        }
+    }
+    __syncthreads();
+    const unsigned st = s_or;
     if (st == 0u) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (host_status) __hip_atomic_fetch_or(host_status, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (model_status) __hip_atomic_fetch_or(model_status, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (host_status) {
+            if (s_lo) __hip_atomic_fetch_or(host_status + 2, s_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (s_hi) __hip_atomic_fetch_or(host_status + 3, s_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_fetch_or(host_status, st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (model_status) __hip_atomic_fetch_or(model_status, st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     const long step = (long)gridDim.x * blockDim.x, i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const float qnan = __builtin_nanf("");
@@ -875,9 +895,31 @@ int launch_fill_u32(void* p, unsigned value, size_t n_bytes, hipStream_t s) {
     return 0;
 }
 
-int launch_plan_guard(const unsigned* status, unsigned* host_status, unsigned* model_status, int64_t* codes, long n_codes,
+int launch_plan_guard(const unsigned* status, int nwords, int site0, unsigned* host_status, unsigned* model_status, int64_t* codes, long n_codes,
                       float* f0, long n0, float* f1, long n1, float* f2, long n2, hipStream_t s) {
-    hipLaunchKernelGGL(plan_guard_kernel, dim3(256), dim3(256), 0, s, status, host_status, model_status, codes, n_codes, f0, n0, f1, n1, f2, n2);
+    if (nwords < 1 || nwords > 256) { set_error("plan_guard: control block size"); return -1; }
+    hipLaunchKernelGGL(plan_guard_kernel, dim3(256), dim3(256), 0, s, status, nwords, site0, host_status, model_status, codes, n_codes, f0, n0, f1, n1, f2, n2);
+    WT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// Largest |hi + lo * 2^-11| over an S32 array of `numel` fp32-equivalent elements, as the bit pattern of a non-negative float
+// (which orders like an unsigned integer): the range report of a plan (WT_PLAN_FLAG_RANGE_REPORT).  NaNs are skipped, an
+// infinite hi half (a value beyond the f16 range) reads as +inf.
+__global__ __launch_bounds__(256) void s32_amax_kernel(const _Float16* __restrict__ p, long numel, unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < numel; e += (long)gridDim.x * blockDim.x) {
+        const long g = (e >> 5) * 64 + (e & 31);
+        m = fmaxf(m, fabsf((float)p[g] + (float)p[g + 32] * (1.f / 2048.f)));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+int launch_s32_amax(const void* s32, long numel, unsigned* out_bits, hipStream_t s) {
+    if (numel <= 0) return 0;
+    const long blocks = (numel + 255) / 256 < 2048 ? (numel + 255) / 256 : 2048;
+    hipLaunchKernelGGL(s32_amax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const _Float16*>(s32), numel, out_bits);
     WT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -6,8 +6,14 @@ namespace wt {
 
 // The dense chain runs on S32 operands (the shipped path) unless the unfused debug plan or fp32 GEMMs are asked for, or
 // the model's weights do not fit the split-f16 range (wt_model::s32_ok)
+static bool site_fp32(const wt_plan* P, int site) { return (P->fp32_sites >> site) & 1u; }
 static bool plan_fp32(const wt_plan* P) {
-    return (P->flags & WT_PLAN_FLAG_FP32_GEMM) || !P->model->s32_ok || (P->kind == WT_PLAN_SEANET_DECODER && !P->model->sd_s32_ok);
+    if ((P->flags & WT_PLAN_FLAG_FP32_GEMM) || !P->model->s32_ok) return true;
+    // plans that are one range site as a whole (model.h Site); the decode plan decides site by site (build_decode)
+    if (P->kind == WT_PLAN_SEANET_DECODER) return !P->model->sd_s32_ok || site_fp32(P, SITE_SEADEC);
+    if (P->kind == WT_PLAN_ENCODE || P->kind == WT_PLAN_UNIT_LSTM) return site_fp32(P, SITE_ENC);
+    if (P->kind == WT_PLAN_HEAD) return site_fp32(P, SITE_HEAD);
+    return false;
 }
 static bool plan_unfused(const wt_plan* P) { return P->flags & WT_PLAN_FLAG_UNFUSED; }
 static bool plan_s32(const wt_plan* P) { return !plan_unfused(P) && !plan_fp32(P); }
@@ -146,7 +152,7 @@ static int plan_lstm(wt_plan* P, const LstmW& w, int B, int L, int H, int xin, c
     });
     // one persistent launch for the whole recurrence (lstm_persist.hip) when the batch fits its per-XCD clip groups and
     // the device is a full MI355X (256 CUs: one resident workgroup per CU, 32 per XCD)
-    static const bool persist_env = [] { const char* e = getenv("WT_LSTM_PERSIST"); return !e || e[0] != '0'; }();
+    const bool persist_env = [] { const char* e = lab_env("WT_LSTM_PERSIST"); return !e || e[0] != '0'; }();       // (LAB builds; callers use WT_PLAN_FLAG_STEP_LSTM)
     bool persist = persist_env && !plan_fp32(P) && !(P->flags & WT_PLAN_FLAG_STEP_LSTM) && w.Wp && H == 512 && B <= 128 && L < 65536;
     if (persist) {
         int cus = 0;
@@ -160,7 +166,7 @@ static int plan_lstm(wt_plan* P, const LstmW& w, int B, int L, int H, int xin, c
             float* hb = P->ptr(c, hx);
             if (int rc = launch_fill_u32(hb, 0xFFFFFFFFu, (hxn + ctn) * sizeof(float), c.stream)) return rc;
             LstmPersistArgs pa;
-            static const int df_trace = [] { const char* e = getenv("WT_LSTM_TRACE"); return e ? atoi(e) : 0; }();
+            const int df_trace = [] { const char* e = lab_env("WT_LSTM_TRACE"); return e ? atoi(e) : 0; }();
             pa.data_flag = 1 | (df_trace ? 4 : 0);
             pa.xg0 = P->ptr(c, xg); pa.Wp = w.Wp; pa.b1 = w.b1; pa.x = P->ptr(c, xin); pa.y = P->ptr(c, y);
             pa.hx = hb; pa.ctl = reinterpret_cast<unsigned*>(hb + hxn);
@@ -194,7 +200,7 @@ static int plan_resblock_s32(wt_plan* P, const ConvW& c3, const ConvW& c1, const
         if (x_bstride) a.a_bstride = x_bstride;
         return gemm_s32(P, a, EPI_BIAS_ELU, OUT_S32, c.stream);
     });
-    static const bool cat_env = [] { const char* e = getenv("WT_RESBLOCK_CAT"); return !e || e[0] != '0'; }();      // A/B timing
+    const bool cat_env = [] { const char* e = lab_env("WT_RESBLOCK_CAT"); return !e || e[0] != '0'; }();      // A/B timing (LAB builds)
     if (cat && cat->w && cat_env && P->model->s32.count(cat->w)) {
         // shortcut + conv1 as one GEMM over K = [x (C) | elu(h) (C/2)] (GemmArgs::A2): the fp32 shortcut tensor is neither
         // written nor read back, and the output goes through the staged full-line epilogue
@@ -261,7 +267,7 @@ int build_encode(wt_plan* P) {
         bool x_is_s32;                   // the resblock output (elu'd) is S32
         // stage 1 of the shipped plan: first conv + resblock + ELU + down conv in ONE kernel, the stage's activations never
         // leave LDS (resblock16.hip, DOWN).  WT_RB16_DOWN=0 keeps the two launches (A/B timing).
-        static const bool down_env = [] { const char* e = getenv("WT_RB16_DOWN"); return !e || e[0] != '0'; }();
+        const bool down_env = [] { const char* e = lab_env("WT_RB16_DOWN"); return !e || e[0] != '0'; }();
         const bool fuse_down = down_env && fused && idx == 1 && fold_e0 && ws32 &&
                                si + 1 < M->stages.size() && resblock_fusable(M->stages[si + 1].C) && st.down.cin == 32 &&
                                st.down.cout == 64 && resblock16_down_fusable(st.C, Tc, st.r, st.down.k);
@@ -397,14 +403,18 @@ int build_decode(wt_plan* P) {
     const int Lp = ((L + 31) / 32) * 32;
     // S32 mode: every operand of the dense chain is written pre-split by its producer (transpose, norm kernels,
     // GELU / head epilogues) and multiplied by gemm16s.hip; the residual stream and the norm inputs stay fp32
-    const bool s32 = plan_s32(P) && (Cin % 32 == 0) && (D % 32 == 0) && (I % 32 == 0);
-    const int x0 = P->buf("bb.in", (size_t)Mrows * Cin, s32 ? BUF_S32 : BUF_F32);
-    P->step({x0}, [=](const RunCtx& c) { return launch_transpose(c.in_f, P->ptr(c, x0), B, Cin, L, c.stream, s32); });
+    const bool s32_plan = plan_s32(P) && (Cin % 32 == 0) && (D % 32 == 0) && (I % 32 == 0);
+    // ... site by site (model.h Site): a site listed in fp32_sites keeps fp32 operands and runs its GEMMs on gemm.hip
+    auto s32_at = [&](int site) { return s32_plan && !site_fp32(P, site); };
+    P->cur_site = SITE_BB_EMBED;
+    const bool s32_e = s32_at(SITE_BB_EMBED);
+    const int x0 = P->buf("bb.in", (size_t)Mrows * Cin, s32_e ? BUF_S32 : BUF_F32);
+    P->step({x0}, [=](const RunCtx& c) { return launch_transpose(c.in_f, P->ptr(c, x0), B, Cin, L, c.stream, s32_e); });
     const int x = P->buf("bb.x", (size_t)Mrows * D);       // residual stream, updated in place
     GemmArgs ae = zconv_args(M->bb_embed, B, L);
     P->step({x0, x}, [=](const RunCtx& c) {
         GemmArgs a = ae; a.A = P->ptr(c, x0); a.C = P->ptr(c, x);
-        if (s32) return gemm_s32(P, a, EPI_BIAS, 0, c.stream);
+        if (s32_e) return gemm_s32(P, a, EPI_BIAS, 0, c.stream);
         return gemm_auto(P, a, PRO_NONE, EPI_BIAS, c.stream);
     });
     const bool keep = P->flags & WT_PLAN_FLAG_KEEP_STAGES;
@@ -419,13 +429,16 @@ int build_decode(wt_plan* P) {
     snapshot("bb.embed");
     const int sc = P->buf("bb.gn_scale", (size_t)B * D), sh = P->buf("bb.gn_shift", (size_t)B * D);
     const int gp = P->buf("bb.gn_part", gn_part_floats(B, L, 32));       // chunk statistics (long clips)
-    const int h1 = P->buf("bb.h1", (size_t)Mrows * D, s32 ? BUF_S32 : BUF_F32);
+    const int h1 = P->buf("bb.h1", (size_t)Mrows * D, s32_plan ? BUF_S32 : BUF_F32);
     const int h2 = P->buf("bb.h2", (size_t)Mrows * D);
 
     // ResnetBlock (models.py:58-78).  GroupNorm+swish is applied ONCE per element by the statistics
     // kernel (a second pass over its own L x 24 slab) instead of in the conv's operand staging,
     // where every element would be re-normalised by each of the 18 (tap, column-tile) re-reads.
-    auto resnet = [&](const PosRes& r, const std::string& name) {
+    auto resnet = [&](const PosRes& r, const std::string& name, int site) {
+        P->cur_site = site;
+        const bool s32 = s32_at(site);
+        P->bufs[h1].fmt = s32 ? BUF_S32 : BUF_F32;         // (h1 is shared by the sites; the range report reads the format per step)
         P->step({x, sc, sh, h1, gp}, [=](const RunCtx& c) {
             return launch_gn_apply(P->ptr(c, x), r.n1w, r.n1b, P->ptr(c, sc), P->ptr(c, sh), P->ptr(c, h1), 1, B, L, D, 32, 1e-6f, c.stream, s32, P->ptr(c, gp));
         }, 1, "res.gn1");
@@ -446,16 +459,18 @@ int build_decode(wt_plan* P) {
         }, 1, "res.conv2");
         snapshot(name);
     };
-    resnet(M->res[0], "bb.pos_net.0");
-    resnet(M->res[1], "bb.pos_net.1");
-    if (s32 && M->s32.count(M->at_Wqk) && M->s32.count(M->at_Wv) && M->s32.count(M->at_Wp)) {
+    resnet(M->res[0], "bb.pos_net.0", SITE_RES0);
+    resnet(M->res[1], "bb.pos_net.1", SITE_RES1);
+    P->cur_site = SITE_ATTN;
+    if (s32_at(SITE_ATTN) && M->s32.count(M->at_Wqk) && M->s32.count(M->at_Wv) && M->s32.count(M->at_Wp)) {
+        P->bufs[h1].fmt = BUF_S32;
         // AttnBlock (models.py:107-127), single head of width D, every product on split-f16 MFMAs: the normalised
         // input, q | k, V^T, the probabilities and the attention output are all written pre-split by their producers
-        const int qk = P->buf("bb.attn.qk", (size_t)Mrows * 2 * D);          // S32 [M][q | k]
-        const int vt = P->buf("bb.attn.vt", (size_t)B * D * Lp);              // S32 [B][D][Lp]
+        const int qk = P->buf("bb.attn.qk", (size_t)Mrows * 2 * D, BUF_S32);          // S32 [M][q | k]
+        const int vt = P->buf("bb.attn.vt", (size_t)B * D * Lp, BUF_S32);              // S32 [B][D][Lp]
         const int S = P->buf("bb.attn.s", (size_t)Mrows * Lp);                // fp32 scores
-        const int Ps = P->buf("bb.attn.p", (size_t)Mrows * Lp);               // S32 probabilities
-        const int o = P->buf("bb.attn.o", (size_t)Mrows * D);                 // S32
+        const int Ps = P->buf("bb.attn.p", (size_t)Mrows * Lp, BUF_S32);               // S32 probabilities
+        const int o = P->buf("bb.attn.o", (size_t)Mrows * D, BUF_S32);                 // S32
         P->step({x, sc, sh, gp, h1}, [=](const RunCtx& c) {
             return launch_gn_apply(P->ptr(c, x), M->at_nw, M->at_nb, P->ptr(c, sc), P->ptr(c, sh), P->ptr(c, h1), 0, B, L, D, 32, 1e-6f, c.stream, 1, P->ptr(c, gp));
         }, 1, "attn.gn");
@@ -497,6 +512,7 @@ int build_decode(wt_plan* P) {
         snapshot("bb.pos_net.2");
     } else
     {   // AttnBlock (models.py:107-127), single head of width D
+        P->bufs[h1].fmt = BUF_F32;
         const int qk = P->buf("bb.attn.qk", (size_t)Mrows * 2 * D);
         const int vt = P->buf("bb.attn.vt", (size_t)B * D * Lp);
         const int S = P->buf("bb.attn.s", (size_t)Mrows * Lp);
@@ -538,8 +554,9 @@ int build_decode(wt_plan* P) {
         });
         snapshot("bb.pos_net.2");
     }
-    resnet(M->res[2], "bb.pos_net.3");
-    resnet(M->res[3], "bb.pos_net.4");
+    resnet(M->res[2], "bb.pos_net.3", SITE_RES2);
+    resnet(M->res[3], "bb.pos_net.4", SITE_RES3);
+    P->cur_site = SITE_CNX0;
     // pos_net[5] GroupNorm + backbone.norm AdaLayerNorm (models.py:213,228), fused into one row pass
     const int xc = P->buf(keep ? "bb.x2" : "bb.norm", (size_t)Mrows * D);
     P->step({x, gp, sc, sh}, [=](const RunCtx& c) {
@@ -557,10 +574,13 @@ int build_decode(wt_plan* P) {
         });
     }
     // ConvNeXt blocks (modules.py:43-60); xc is the residual stream from here on
-    const int nrm = P->buf("bb.cnx.norm", (size_t)Mrows * D, s32 ? BUF_S32 : BUF_F32);
-    const int mid = P->buf("bb.cnx.mid", (size_t)Mrows * I, s32 ? BUF_S32 : BUF_F32);
+    const int nrm = P->buf("bb.cnx.norm", (size_t)Mrows * D, s32_plan ? BUF_S32 : BUF_F32);
+    const int mid = P->buf("bb.cnx.mid", (size_t)Mrows * I, s32_plan ? BUF_S32 : BUF_F32);
     for (int i = 0; i < ar.num_layers; ++i) {
         const CnxBlock cb = M->cnx[i];
+        P->cur_site = SITE_CNX0 + i;
+        const bool s32 = s32_at(SITE_CNX0 + i);
+        P->bufs[nrm].fmt = P->bufs[mid].fmt = s32 ? BUF_S32 : BUF_F32;
         P->step({xc, nrm}, [=](const RunCtx& c) {
             return launch_rownorm(RN_DWCONV, P->ptr(c, xc), P->ptr(c, nrm), B, L, D, cb.dw_w, cb.dw_b, nullptr, nullptr,
                                   cb.ada_s + (size_t)c.bw_id * D, cb.ada_h + (size_t)c.bw_id * D, 1e-6f, c.stream, s32);
@@ -585,6 +605,8 @@ int build_decode(wt_plan* P) {
             });
         }
     }
+    P->cur_site = SITE_HEAD;
+    const bool s32 = s32_at(SITE_HEAD);
     const int xo = P->buf("bb.out", (size_t)Mrows * D, s32 ? BUF_S32 : BUF_F32);
     P->step({xc, xo}, [=](const RunCtx& c) {
         if (int rc = launch_rownorm(RN_PLAIN, P->ptr(c, xc), P->ptr(c, xo), B, L, D, nullptr, nullptr, nullptr, nullptr,
@@ -604,8 +626,9 @@ int build_head(wt_plan* P) {
     const wt_model* M = P->model;
     const int B = P->B, L = (int)P->L, D = M->arch.dim;
     const long Mrows = (long)B * L;
+    P->cur_site = SITE_HEAD;
     const bool s32 = plan_s32(P) && (D % 32 == 0) && M->s32.count(M->head_W) && M->s32.count(M->istft_W);
-    const int xo = P->buf("head.in", (size_t)Mrows * D);
+    const int xo = P->buf("head.in", (size_t)Mrows * D, s32 ? BUF_S32 : BUF_F32);
     P->step({xo}, [=](const RunCtx& c) {
         if (s32) return launch_split_s32(c.in_f, P->ptr(c, xo), Mrows * D, c.stream);
         WT_HIP_CHECK(hipMemcpyAsync(P->ptr(c, xo), c.in_f, (size_t)Mrows * D * sizeof(float), hipMemcpyDeviceToDevice, c.stream));
@@ -685,6 +708,7 @@ int build_seanet_decoder(wt_plan* P) {
     const wt_model* M = P->model;
     if (!M->has_seadec) { set_error("checkpoint holds no SEANetDecoder weights"); return WT_ERR_MISSING_TENSOR; }
     const int B = P->B, L = (int)P->L, H = M->H;
+    P->cur_site = SITE_SEADEC;
     if (seadec_s32_ok(P)) return build_seanet_decoder_s32(P);
     const int x0 = P->buf("sdec.in", (size_t)B * L * 512);
     P->step({x0}, [=](const RunCtx& c) { return launch_transpose(c.in_f, P->ptr(c, x0), B, 512, L, c.stream); });
@@ -747,10 +771,10 @@ int build_seanet_decoder(wt_plan* P) {
 
 // Every plan starts by zeroing its control block (word 0 = the call's status, common.h) and ends with the guard step
 void plan_begin(wt_plan* P) {
-    P->ctl = P->buf("ctl", 64);
+    P->ctl = P->buf("ctl", CTL_WORDS);
     const int ctl = P->ctl;
     P->step({ctl}, [=](const RunCtx& c) {
-        return launch_fill_u32(P->ptr(c, ctl), 0u, 256, c.stream);
+        return launch_fill_u32(P->ptr(c, ctl), 0u, CTL_WORDS * sizeof(unsigned), c.stream);
     }, 1, "ctl.clear");
 }
 
@@ -767,8 +791,8 @@ void plan_end(wt_plan* P) {
         else if (kind == WT_PLAN_UNIT_LSTM) { n0 = B * L * 512; f1 = nullptr; }
         else if (kind == WT_PLAN_HEAD) { n0 = B * wave_samples(M, L); f1 = nullptr; }
         else { n0 = B * L * hop; f1 = nullptr; }
-        return launch_plan_guard(reinterpret_cast<const unsigned*>(P->ptr(c, ctl)), P->status_dev, M->status_dev, codes, nc, c.out_f, n0,
-                                 f1, n1, nullptr, 0, c.stream);
+        return launch_plan_guard(reinterpret_cast<const unsigned*>(P->ptr(c, ctl)), CTL_WORDS, CTL_SITE0, P->status_dev, M->status_dev, codes,
+                                 nc, c.out_f, n0, f1, n1, nullptr, 0, c.stream);
     }, 1, "guard");
 }
 

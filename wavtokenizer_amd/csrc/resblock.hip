@@ -244,7 +244,8 @@ static int launch_rb(const ResblockArgs& a, hipStream_t s) {
     })) return rc;
     const long tiles = (long)a.B * ((a.T + ROWS - 1) / ROWS);
     const int per_cu = (int)(160 * 1024 / smem) < 4 ? (int)(160 * 1024 / smem) : 4;
-    const long grid = tiles < 256L * per_cu ? tiles : 256L * per_cu;
+    const long slots = (long)device_cus() * per_cu;
+    const long grid = tiles < slots ? tiles : slots;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(ROWS * 2), smem, s, a);
     WT_HIP_CHECK(hipGetLastError());
     return 0;

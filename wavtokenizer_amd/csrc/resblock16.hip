@@ -695,19 +695,24 @@ static int launch_rb16(const ResblockArgs& a, hipStream_t s) {
     static_assert(smem <= 160 * 1024, "LDS budget");
     auto kern = resblock16_kernel<C, ROWS, FOLD, false, 0, FPW>;
     int dbg_req = 0;
-    if (const char* e = getenv("WT_RB16_DBG")) dbg_req = atoi(e);
+#ifdef WT_LAB       // the phase-ablation instantiations (tools/rb16_bench.py, WT_RB16_DBG) exist in LAB builds only
+    if (const char* e = lab_env("WT_RB16_DBG")) dbg_req = atoi(e);
     if (dbg_req) kern = resblock16_kernel<C, ROWS, FOLD, true, 0, FPW>;
+#endif
     if (int rc = attr_once.run([&]() -> int {
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock16_kernel<C, ROWS, FOLD, false, 0, FPW>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+#ifdef WT_LAB
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock16_kernel<C, ROWS, FOLD, true, 0, FPW>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+#endif
         return 0;
     })) return rc;
     constexpr int VALID = FOLD ? ROWS - 2 : ROWS;
     const long tiles = (long)a.B * ((a.T + VALID - 1) / VALID);
     const int per_cu = (int)(160 * 1024 / smem) < 4 ? (int)(160 * 1024 / smem) : 4;
-    const long grid = tiles < 256L * per_cu ? tiles : 256L * per_cu;
+    const long slots = (long)device_cus() * per_cu;
+    const long grid = tiles < slots ? tiles : slots;
     ResblockArgs b = a;
     b.dbg = dbg_req;
     if (!b.status) b.status = g_launch.status;
@@ -724,18 +729,23 @@ static int launch_rb16_down(const ResblockArgs& a, hipStream_t s) {
     constexpr int OPT = (126 - 2 * R) / R + 1;
     auto kern = resblock16_kernel<32, 128, 1, false, R>;
     int dbg_req = 0;
-    if (const char* e = getenv("WT_RB16_DBG")) dbg_req = atoi(e);
+#ifdef WT_LAB
+    if (const char* e = lab_env("WT_RB16_DBG")) dbg_req = atoi(e);
     if (dbg_req) kern = resblock16_kernel<32, 128, 1, true, R>;
+#endif
     if (int rc = attr_once.run([&]() -> int {
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock16_kernel<32, 128, 1, false, R>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+#ifdef WT_LAB
         WT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock16_kernel<32, 128, 1, true, R>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+#endif
         return 0;
     })) return rc;
     const long tiles = (long)a.B * (((a.T + R - 1) / R + OPT - 1) / OPT);
     const int per_cu = (int)(160 * 1024 / smem) < 4 ? (int)(160 * 1024 / smem) : 4;
-    const long grid = tiles < 256L * per_cu ? tiles : 256L * per_cu;
+    const long slots = (long)device_cus() * per_cu;
+    const long grid = tiles < slots ? tiles : slots;
     ResblockArgs b = a;
     b.dbg = dbg_req;
     if (!b.status) b.status = g_launch.status;
@@ -762,8 +772,10 @@ int launch_resblock16(const ResblockArgs& a, hipStream_t s) {
     if (a.C == 64) {
         // A/B timing: WT_RB16_FPW=32 is the 4-wave form.  (Tried: 48-row tiles of 3 waves, 75 KB, i.e. two independent
         // workgroups per CU: 252 us against 223 for the 8-wave form and 268 for the 4-wave form, kernel alone, one box.)
-        static const bool fpw32 = [] { const char* e = getenv("WT_RB16_FPW"); return e && atoi(e) == 32; }();
-        return fpw32 ? launch_rb16<64, 128, 0, 32>(a, s) : launch_rb16<64, 128, 0, 16>(a, s);
+#ifdef WT_LAB
+        if (const char* e = lab_env("WT_RB16_FPW")) if (atoi(e) == 32) return launch_rb16<64, 128, 0, 32>(a, s);
+#endif
+        return launch_rb16<64, 128, 0, 16>(a, s);
     }
     set_error("resblock16: fused kernel exists for C = 32 and 64");
     return -1;

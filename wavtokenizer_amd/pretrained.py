@@ -161,7 +161,12 @@ class _Engine:
         # their workspaces exceed max_ws_bytes (a file-by-file caller meets a new length, hence a new plan, per file)
         self.max_plans = int(os.environ.get("WAVTOK_MAX_PLANS", "64"))
         self.max_ws_bytes = int(float(os.environ.get("WAVTOK_MAX_WORKSPACE_GB", "16")) * (1 << 30))
-        self.plans: Dict[Tuple[int, int, int, int], Tuple[ctypes.c_void_p, torch.Tensor]] = {}
+        # plans are per HIP stream (a plan owns a workspace): at most this many non-default streams keep plans at a time; a
+        # caller that makes a new stream (or takes one of torch's 32 pooled side streams) per request would otherwise fill the
+        # LRU with plans + workspaces + recorded graphs of streams it never uses again (the least recently used stream goes first)
+        self.max_streams = int(os.environ.get("WAVTOK_MAX_STREAMS", "4"))
+        self.stream_lru: List[int] = []
+        self.plans: Dict[tuple, Tuple[ctypes.c_void_p, torch.Tensor]] = {}
         self.io: Dict[Tuple[int, int, int, int], Dict[str, torch.Tensor]] = {}     # fixed I/O buffers of graph plans
         self.device_index = -1
         self._keepalive: List[Any] = []
@@ -219,21 +224,37 @@ class _Engine:
         return buf[:used] if 0 < used <= n else buf
 
     @staticmethod
-    def _key(kind: int, B: int, length: int, flags: int, device) -> tuple:
+    def _key(kind: int, B: int, length: int, flags: int, device, sites: int = 0) -> tuple:
         """A plan owns a workspace, so it serves ONE stream: calls made under another current stream than the default one
         get plans (and staging buffers) of their own, keyed (..., stream handle).  Two streams can then run the same model
-        side by side (sharding.StepRunner(lanes=2)); the library orders their persistent LSTM launches itself (capi.cpp)."""
+        side by side (sharding.StepRunner(lanes=2)); the library orders their persistent LSTM launches itself (capi.cpp).
+        Key: (kind, B, length, flags) on the default stream, + (stream,) on another one, + (stream, fp32 site mask) for a
+        plan with range sites on fp32 operands (stream 0 = the default stream)."""
         sp = torch.cuda.current_stream(device).cuda_stream if device is not None else 0
+        if sites:
+            return (kind, B, length, flags, sp, sites)
         return (kind, B, length, flags) if not sp else (kind, B, length, flags, sp)
 
-    def plan(self, kind: int, B: int, length: int, flags: int, device: torch.device):
-        key = self._key(kind, B, length, flags, device)
+    def _touch_stream(self, sp: int):
+        if not sp:
+            return
+        if sp in self.stream_lru:
+            self.stream_lru.remove(sp)
+        self.stream_lru.append(sp)
+        while len(self.stream_lru) > self.max_streams:
+            old = self.stream_lru.pop(0)
+            self.drop(lambda k: len(k) >= 5 and k[4] == old)
+
+    def plan(self, kind: int, B: int, length: int, flags: int, device: torch.device, sites: int = 0):
+        key = self._key(kind, B, length, flags, device, sites)
         hit = self.plans.pop(key, None)
         if hit is not None:
             self.plans[key] = hit                     # most recently used last (dicts keep insertion order)
             return hit
+        if len(key) >= 5:
+            self._touch_stream(key[4])
         p = ctypes.c_void_p()
-        check(lib.wt_plan_create(self.model, kind, B, length, flags, ctypes.byref(p)), "wt_plan_create")
+        check(lib.wt_plan_create_ex(self.model, kind, B, length, flags, sites, ctypes.byref(p)), "wt_plan_create")
         need = lib.wt_plan_workspace_bytes(p)
         while self.plans and (len(self.plans) >= self.max_plans or
                               sum(w.numel() for _p, w in self.plans.values()) + need > self.max_ws_bytes):
@@ -250,14 +271,25 @@ class _Engine:
             lib.wt_plan_destroy(self.plans.pop(k)[0])
             self.io.pop(k, None)
 
-    def staging(self, kind: int, B: int, length: int, flags: int, make, device=None) -> Dict[str, torch.Tensor]:
+    def staging(self, kind: int, B: int, length: int, flags: int, make, device=None, sites: int = 0) -> Dict[str, torch.Tensor]:
         """Fixed input/output tensors of a graph plan: a recorded hipGraph replays fixed addresses, so calls copy their
         input in and hand out copies of the results (a few hundred KB at the batch sizes graphs are used for)."""
-        key = self._key(kind, B, length, flags, device)
+        key = self._key(kind, B, length, flags, device, sites)
         io = self.io.get(key)
         if io is None:
             io = self.io[key] = make()
         return io
+
+
+def site_name(site: int) -> str:
+    """Range site (include/wavtokenizer_amd.h wt_range_site) -> the reference module it covers."""
+    names = {_capi.WT_SITE_ENCODER: "feature_extractor.encodec.encoder + quantizer", _capi.WT_SITE_BB_EMBED: "backbone.embed",
+             _capi.WT_SITE_RES0: "backbone.pos_net.0", _capi.WT_SITE_RES1: "backbone.pos_net.1", _capi.WT_SITE_ATTN: "backbone.pos_net.2",
+             _capi.WT_SITE_RES2: "backbone.pos_net.3", _capi.WT_SITE_RES3: "backbone.pos_net.4", _capi.WT_SITE_HEAD: "backbone.final_layer_norm + head",
+             _capi.WT_SITE_SEANET_DECODER: "feature_extractor.encodec.decoder"}
+    if _capi.WT_SITE_CNX0 <= site < _capi.WT_SITE_HEAD:
+        return "backbone.convnext.%d" % (site - _capi.WT_SITE_CNX0)
+    return names.get(site, "site %d" % site)
 
 
 def _stream_ptr(device: torch.device) -> ctypes.c_void_p:
@@ -282,13 +314,22 @@ class WavTokenizer(nn.Module):
         self._engine = _Engine()
         self._dirty = True
         self._plan_flags = 0
-        self._strict = os.environ.get("WAVTOK_STRICT_STATUS", "0") == "1"
-        # codes_to_features and indices outside the codebook (F.embedding raises IndexError, pretrained.py:236): "deferred"
-        # (default) raises on the NEXT call on this model or in check_status() without synchronising the stream, like the
-        # reference's CUDA F.embedding, whose device-side assert also surfaces later; "sync" synchronises after the gather
-        # and raises at once; "off" never looks.  The gathered features of a bad index are NaN in every mode.
-        self._check_codes = {"1": "deferred", "0": "off"}.get(os.environ.get("WAVTOK_CHECK_CODES", "deferred"),
-                                                              os.environ.get("WAVTOK_CHECK_CODES", "deferred"))
+        self._fp32_sites = 0                 # range sites (_capi.WT_SITE_*) that have left the split-f16 form after an overflow
+        # strict status: None (default) = automatic: calls of up to _graph_max_clips clips (graph-replayed, bound by the host
+        # anyway: the reference's own file-by-file usage) synchronise, check and REPEAT a failed call on the fallback path, so
+        # an infer.py-style caller is never handed poisoned tensors; larger batches stay asynchronous and report on the next
+        # call.  WAVTOK_STRICT_STATUS=1 / 0 or set_strict_status force it on / off for every size
+        env_strict = os.environ.get("WAVTOK_STRICT_STATUS")
+        self._strict = None if env_strict is None else env_strict == "1"
+        # codes_to_features and indices outside the codebook (F.embedding raises IndexError, pretrained.py:236): "sync"
+        # (default) synchronises after the gather (a few microseconds of work) and raises for the offending call, like the
+        # reference on the CPU; "deferred" (opt-in, for pipelines that must not synchronise) raises on the NEXT call on this
+        # model or in check_status(); "off" never looks.  The gathered features of a bad index are NaN in every mode.
+        env_cc = os.environ.get("WAVTOK_CHECK_CODES", "sync")
+        env_cc = {"1": "sync", "0": "off"}.get(env_cc, env_cc)
+        if env_cc not in ("sync", "deferred", "off"):
+            raise ValueError(f"WAVTOK_CHECK_CODES={env_cc!r}: use sync (or 1), deferred or off (or 0)")
+        self._check_codes = env_cc
         self._bw_cache = None                # (tensor ref, version, index): bandwidth_id tensors living on the GPU
         self.fallback_events: List[str] = []   # device-side failures this model has answered by falling back (check_status reports them)
         # batches up to this many clips are replayed as one hipGraph per (shape) plan: they are bound by the host's
@@ -479,8 +520,14 @@ class WavTokenizer(nn.Module):
         NEXT call on this model, whatever its shape (the library keeps one host-mapped status word per model beside the
         per-plan ones), which this class answers by falling back for good (fp32 GEMMs / launch-per-step LSTM for every
         plan of the model) and running that next call.  strict=True additionally synchronises after every call, checks, falls back and REPEATS
-        the failed call itself, so no poisoned result is ever handed out (costs the host/GPU overlap between calls)."""
-        self._strict = bool(on)
+        the failed call itself, so no poisoned result is ever handed out (costs the host/GPU overlap between calls).
+        Default (None): strict for calls of up to the graph batch limit (16 clips), asynchronous above."""
+        self._strict = None if on is None else bool(on)
+
+    def _is_strict(self, B: int) -> bool:
+        if self._strict is None:
+            return 0 < B <= self._graph_max_clips
+        return self._strict
 
     def check_status(self):
         """Synchronise and raise WavTokError if any call since the last check failed on the device: failures still pending
@@ -501,7 +548,7 @@ class WavTokenizer(nn.Module):
             if bits.value:
                 seen.append((key, bits.value))
         if mbits.value & _capi.WT_STATUS_BIT_RANGE:
-            self._plan_flags |= _capi.WT_PLAN_FLAG_FP32_GEMM
+            self._answer_range()
         bad = (seen or [("model", mbits.value)]) if mbits.value else []
         events, self.fallback_events = self.fallback_events, []
         if events and not bad:
@@ -509,7 +556,25 @@ class WavTokenizer(nn.Module):
         self._poll_bad_codes()
         if bad:
             raise WavTokError("device-side failure in earlier calls (plan key, status bits): %s; their outputs were "
-                              "overwritten with -1 / NaN; later calls fall back (fp32 GEMMs / step LSTM)" % bad)
+                              "overwritten with -1 / NaN; later calls fall back (fp32 operands at the reporting site / step LSTM)" % bad)
+
+    def _answer_range(self) -> str:
+        """An S32 producer met |v| >= 65504.  The plans know which range sites reported (wt_plan_range_sites): the LOWEST
+        one that is still on split-f16 operands goes to fp32 operands (its GEMMs then run on the fp32 MFMA chain; sites
+        behind it usually report as well, because infinities propagate, and are left alone until they report on their
+        own).  Without attribution (the plan is gone) the whole model falls back, as in round 3."""
+        mask = 0
+        for plan, _ws in self._engine.plans.values():
+            m = ctypes.c_uint64()
+            check(lib.wt_plan_range_sites(plan, ctypes.byref(m), 1), "wt_plan_range_sites")
+            mask |= m.value
+        new = mask & ~self._fp32_sites
+        if new:
+            site = (new & -new).bit_length() - 1
+            self._fp32_sites |= 1 << site
+            return "range site %d (%s) now keeps fp32 operands" % (site, site_name(site))
+        self._plan_flags |= _capi.WT_PLAN_FLAG_FP32_GEMM
+        return "no site attribution left: the whole model now runs fp32 GEMMs"
 
     def set_gemm_precision(self, mode: str):
         """"f16x3" (default): dense layers on the fp32-equivalent split-f16 MFMA kernel; "f32": the plain
@@ -520,11 +585,18 @@ class WavTokenizer(nn.Module):
             (self._plan_flags & ~_capi.WT_PLAN_FLAG_FP32_GEMM)
 
     def set_check_codes(self, mode: str):
-        """How codes_to_features reports an index outside the codebook: "deferred" (default; IndexError on the next call
-        on this model or in check_status(), no stream synchronisation), "sync" (synchronise and raise at once) or "off"."""
+        """How codes_to_features reports an index outside the codebook: "sync" (default: synchronise and raise for the
+        offending call, like the reference), "deferred" (IndexError on the next call on this model or in check_status(), no
+        stream synchronisation) or "off"."""
         if mode not in ("deferred", "sync", "off"):
             raise ValueError("mode must be 'deferred', 'sync' or 'off'")
         self._check_codes = mode
+
+    @property
+    def persistent_lstm(self) -> bool:
+        """True while this model's plans may launch the persistent LSTM kernel (the library's own word: a 256-CU device and
+        no lost-co-residency report so far)."""
+        return bool(self._engine.model) and bool(lib.wt_model_persistent_lstm(self._engine.model))
 
     def _poll_bad_codes(self):
         if self._check_codes != "off" and self._engine.model and lib.wt_model_take_bad_codes(self._engine.model):
@@ -539,35 +611,92 @@ class WavTokenizer(nn.Module):
             return self._plan_flags | _capi.WT_PLAN_FLAG_GRAPH
         return self._plan_flags
 
-    def _guarded(self, dev: torch.device, get_plan, launch):
+    def _guarded(self, dev: torch.device, get_plan, launch, strict: bool = False):
         """Runs launch(plan, ws) with the fallbacks for device-side failures (set_strict_status).  get_plan() builds the
-        plan from the CURRENT flags, so a fallback that changes them re-plans."""
-        for attempt in range(3):
+        plan from the CURRENT flags and fp32 sites, so a fallback that changes them re-plans."""
+        for attempt in range(8):
             plan, ws = get_plan()
             try:
                 out = launch(plan, ws)
             except WavTokError as e:
-                if e.status == _capi.WT_ERR_LSTM_SYNC and attempt < 2:
+                if e.status == _capi.WT_ERR_LSTM_SYNC and attempt < 7:
                     self.fallback_events.append("persistent LSTM lost co-residency in an earlier call (its outputs were poisoned): "
                                                 "the model now runs the launch-per-step LSTM")
                     continue                                  # the model's plans now run the step LSTM
-                if e.status == _capi.WT_ERR_RANGE and attempt < 2:
+                if e.status == _capi.WT_ERR_RANGE and attempt < 7:
                     self.fallback_events.append("an earlier call left the f16 range of the split-f16 form (its outputs were "
-                                                "poisoned): the model now runs fp32 GEMMs")
-                    self._plan_flags |= _capi.WT_PLAN_FLAG_FP32_GEMM
+                                                "poisoned): " + self._answer_range())
                     continue
                 raise
-            if not self._strict:
+            if not strict:
                 return out
             torch.cuda.current_stream(dev).synchronize()
             bits = ctypes.c_int32()
             check(lib.wt_plan_status(plan, ctypes.byref(bits), 1), "wt_plan_status")
             if not bits.value:
                 return out
-            self.fallback_events.append("strict mode: the call failed on the device (status bits %d) and was repeated on the fallback path" % bits.value)
-            if bits.value & _capi.WT_STATUS_BIT_RANGE:
-                self._plan_flags |= _capi.WT_PLAN_FLAG_FP32_GEMM
+            what = self._answer_range() if bits.value & _capi.WT_STATUS_BIT_RANGE else "launch-per-step LSTM"
+            self.fallback_events.append("strict mode: the call failed on the device (status bits %d) and was repeated on the fallback path: %s" % (bits.value, what))
         raise WavTokError("the call kept failing on the device after the fp32 / step-LSTM fallbacks")
+
+    def _sites(self, kind: int) -> int:
+        """The fp32 range sites that matter to a plan kind (so that an overflow in the decoder does not re-plan the encoder)."""
+        m = self._fp32_sites
+        if kind in (_capi.WT_PLAN_ENCODE, _capi.WT_PLAN_UNIT_LSTM):
+            return m & (1 << _capi.WT_SITE_ENCODER)
+        if kind == _capi.WT_PLAN_HEAD:
+            return m & (1 << _capi.WT_SITE_HEAD)
+        if kind == _capi.WT_PLAN_SEANET_DECODER:
+            return m & (1 << _capi.WT_SITE_SEANET_DECODER)
+        return m & ~((1 << _capi.WT_SITE_ENCODER) | (1 << _capi.WT_SITE_SEANET_DECODER))
+
+    def range_report(self, audio_input: torch.Tensor, bandwidth_id=None) -> List[Dict[str, Any]]:
+        """How far every split-f16 (S32) operand of the dense layers sits below the f16 limit on THIS input with THESE
+        weights: one encode_infer + decode pass on plans created with WT_PLAN_FLAG_RANGE_REPORT (same kernels; behind every
+        step the largest magnitude of each S32 buffer the step touches is measured).  Returns a list of
+        {"plan", "step", "buffer", "amax", "headroom_bits" = log2(65504 / amax)} in execution order; an entry with
+        amax = inf marks a tensor that left the range (the call's outputs are then poisoned, as always)."""
+        import math
+        dev = self._ensure_engine()
+        bw = self._bandwidth_index(bandwidth_id if bandwidth_id is not None else torch.tensor([0]))
+        audio = self._as_input(audio_input, dev)
+        B, T = audio.shape
+        L = self._arch.frames(T)
+        flags = (self._plan_flags | _capi.WT_PLAN_FLAG_RANGE_REPORT) & ~_capi.WT_PLAN_FLAG_GRAPH
+        feats = torch.empty((B, 512, L), dtype=torch.float32, device=dev)
+        codes = torch.empty((1, B, L), dtype=torch.int64, device=dev)
+        wav = torch.empty((B, self._wave_len(L)), dtype=torch.float32, device=dev)
+        out: List[Dict[str, Any]] = []
+
+        def collect(plan, what):
+            i = 0
+            step, buf, amax = ctypes.c_char_p(), ctypes.c_char_p(), ctypes.c_float()
+            while lib.wt_plan_range_report(plan, i, ctypes.byref(step), ctypes.byref(buf), ctypes.byref(amax)) == 0:
+                a = float(amax.value)
+                out.append({"plan": what, "step": step.value.decode(), "buffer": buf.value.decode(), "amax": a,
+                            "headroom_bits": (math.log2(65504.0 / a) if 0.0 < a < float("inf") else (float("inf") if a == 0.0 else float("-inf")))})
+                i += 1
+
+        pe, wse = self._engine.plan(_capi.WT_PLAN_ENCODE, B, T, flags, dev, self._sites(_capi.WT_PLAN_ENCODE))
+        check(lib.wt_encode(pe, _ptr(audio), _ptr(feats), _ptr(codes), _ptr(None), _ptr(wse), _stream_ptr(dev)), "wt_encode")
+        collect(pe, "encode")
+        # the decoder is measured on the features the codes select (finite even if the encoder's own report shows an overflow)
+        torch.cuda.current_stream(dev).synchronize()
+        bits = ctypes.c_int32()
+        check(lib.wt_plan_status(pe, ctypes.byref(bits), 1), "wt_plan_status")
+        check(lib.wt_model_status(self._engine.model, ctypes.byref(bits), 1), "wt_model_status")
+        pd, wsd = self._engine.plan(_capi.WT_PLAN_DECODE, B, L, flags, dev, self._sites(_capi.WT_PLAN_DECODE))
+        fin = feats if torch.isfinite(feats).all() else torch.zeros_like(feats)
+        check(lib.wt_decode(pd, _ptr(fin), bw, _ptr(wav), _ptr(None), _ptr(wsd), _stream_ptr(dev)), "wt_decode")
+        collect(pd, "decode")
+        torch.cuda.current_stream(dev).synchronize()
+        check(lib.wt_plan_status(pd, ctypes.byref(bits), 1), "wt_plan_status")
+        check(lib.wt_model_status(self._engine.model, ctypes.byref(bits), 1), "wt_model_status")
+        m = ctypes.c_uint64()
+        for p in (pe, pd):
+            check(lib.wt_plan_range_sites(p, ctypes.byref(m), 1), "wt_plan_range_sites")
+        self._engine.drop(lambda k: k[3] & _capi.WT_PLAN_FLAG_RANGE_REPORT)
+        return out
 
     def set_lstm_mode(self, mode: str):
         """"persistent" (default): the whole LSTM recurrence in one launch (per-XCD clip groups, weights resident);
@@ -625,7 +754,7 @@ class WavTokenizer(nn.Module):
                     "in": torch.empty((B, T), dtype=torch.float32, device=dev),
                     "feats": torch.empty((B, 512, L), dtype=torch.float32, device=dev),
                     "codes": torch.empty((1, B, L), dtype=torch.int64, device=dev),
-                    "emb": torch.empty((B, 512, L), dtype=torch.float32, device=dev)}, dev)
+                    "emb": torch.empty((B, 512, L), dtype=torch.float32, device=dev)}, dev, self._sites(_capi.WT_PLAN_ENCODE))
                 io["in"].copy_(audio)
                 check(lib.wt_encode(plan, _ptr(io["in"]), _ptr(io["feats"]), _ptr(io["codes"]), _ptr(io["emb"]), _ptr(ws),
                                     _stream_ptr(dev)), "wt_encode")
@@ -637,7 +766,8 @@ class WavTokenizer(nn.Module):
                   "wt_encode")
             return feats, codes, emb
 
-        return self._guarded(dev, lambda: self._engine.plan(_capi.WT_PLAN_ENCODE, B, T, self._graph_flags(B), dev), launch)
+        return self._guarded(dev, lambda: self._engine.plan(_capi.WT_PLAN_ENCODE, B, T, self._graph_flags(B), dev,
+                                                            self._sites(_capi.WT_PLAN_ENCODE)), launch, self._is_strict(B))
 
     def _bandwidth_index(self, bandwidth_id) -> int:
         if bandwidth_id is None:
@@ -674,7 +804,7 @@ class WavTokenizer(nn.Module):
             if flags & _capi.WT_PLAN_FLAG_GRAPH:
                 io = self._engine.staging(_capi.WT_PLAN_DECODE, B, L, flags, lambda: {
                     "in": torch.empty((B, self._arch.input_channels, L), dtype=torch.float32, device=dev),
-                    "wav": torch.empty((B, self._wave_len(L)), dtype=torch.float32, device=dev)}, dev)
+                    "wav": torch.empty((B, self._wave_len(L)), dtype=torch.float32, device=dev)}, dev, self._sites(_capi.WT_PLAN_DECODE))
                 io["in"].copy_(features)
                 check(lib.wt_decode(plan, _ptr(io["in"]), bw, _ptr(io["wav"]), _ptr(None), _ptr(ws), _stream_ptr(dev)), "wt_decode")
                 return io["wav"].clone(), None
@@ -683,7 +813,8 @@ class WavTokenizer(nn.Module):
             check(lib.wt_decode(plan, _ptr(features), bw, _ptr(wav), _ptr(bb), _ptr(ws), _stream_ptr(dev)), "wt_decode")
             return wav, bb
 
-        return self._guarded(dev, lambda: self._engine.plan(_capi.WT_PLAN_DECODE, B, L, cur_flags(), dev), launch)
+        return self._guarded(dev, lambda: self._engine.plan(_capi.WT_PLAN_DECODE, B, L, cur_flags(), dev, self._sites(_capi.WT_PLAN_DECODE)),
+                             launch, self._is_strict(B))
 
     def _run_head(self, x: torch.Tensor) -> torch.Tensor:
         dev = self._ensure_engine()
@@ -696,7 +827,8 @@ class WavTokenizer(nn.Module):
             check(lib.wt_head(plan, _ptr(x), _ptr(wav), _ptr(ws), _stream_ptr(dev)), "wt_head")
             return wav
 
-        return self._guarded(dev, lambda: self._engine.plan(_capi.WT_PLAN_HEAD, B, L, self._plan_flags, dev), launch)
+        return self._guarded(dev, lambda: self._engine.plan(_capi.WT_PLAN_HEAD, B, L, self._plan_flags, dev, self._sites(_capi.WT_PLAN_HEAD)),
+                             launch, self._is_strict(B))
 
     def _run_seanet_decoder(self, z: torch.Tensor) -> torch.Tensor:
         dev = self._ensure_engine()
@@ -708,14 +840,15 @@ class WavTokenizer(nn.Module):
             check(lib.wt_seanet_decode(plan, _ptr(z), _ptr(out), _ptr(ws), _stream_ptr(dev)), "wt_seanet_decode")
             return out
 
-        return self._guarded(dev, lambda: self._engine.plan(_capi.WT_PLAN_SEANET_DECODER, B, L, self._plan_flags, dev), launch)
+        return self._guarded(dev, lambda: self._engine.plan(_capi.WT_PLAN_SEANET_DECODER, B, L, self._plan_flags, dev,
+                                                            self._sites(_capi.WT_PLAN_SEANET_DECODER)), launch, self._is_strict(B))
 
     def _run_unit_lstm(self, x: torch.Tensor) -> torch.Tensor:
         """Unit tests: the encoder's SLSTM alone, x (B, L, 512) time-major -> lstm(x) + x, on the plan's kernels."""
         dev = self._ensure_engine()
         x = self._as_input(x, dev)
         B, L, _ = x.shape
-        plan, ws = self._engine.plan(_capi.WT_PLAN_UNIT_LSTM, B, L, self._plan_flags, dev)
+        plan, ws = self._engine.plan(_capi.WT_PLAN_UNIT_LSTM, B, L, self._plan_flags, dev, self._sites(_capi.WT_PLAN_UNIT_LSTM))
         y = torch.empty_like(x)
         check(lib.wt_unit_run(plan, _ptr(x), _ptr(y), _ptr(ws), _stream_ptr(dev)), "wt_unit_run")
         return y

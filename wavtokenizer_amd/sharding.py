@@ -166,6 +166,9 @@ class StepRunner:
         if self.streams is not None:
             st = self.streams[self.i % self.lanes]
             self.i += 1
+            # the lane starts behind whatever the caller's stream holds (a waveform the caller is still producing there);
+            # the results are ordered with the caller's stream only by drain(): do not read them before
+            st.wait_stream(torch.cuda.current_stream(self.wav.device))
             with torch.cuda.stream(st):
                 feats, codes = self.model.encode_infer(self.wav, bandwidth_id=self.bw)
                 out = self.model.decode(feats, bandwidth_id=self.bw)
