@@ -15,6 +15,13 @@ Timing: W warm-up steps, then R blocks of exactly K steps, each block bracketed 
 torch.cuda.synchronize() on both sides and reduced with MAX over ranks.  `ms_per_step` / `value` are
 the MEDIAN block (a single 0.13 s block is a thin basis: the min / max over the blocks are on the line too).
 
+Schedule of the headline (config.lanes): at N = 1 the K steps of a block are issued alternately on TWO HIP streams
+(sharding.StepRunner(lanes=2): step i+1's encode_infer runs beside step i's decode and fills its launch gaps and last-round
+tails; every step is still one full encode_infer + decode of the batch and all K complete inside the bracket; same kernels,
+same bits).  The one-stream schedule is measured in the same run (config.one_lane) and is what the roofline launch is timed
+in, so that a second stream never lengthens the launch being measured.  `--lanes 1` makes the one-stream schedule the
+headline.  N > 1 keeps one lane (the end-of-step exchange is ordered against the persistent LSTM on one stream: DESIGN 6).
+
 Extra objects on the line:
   roofline      — dominant kernel (ConvNeXt pwconv1 GEMM + GELU, 12 launches per step): achieved =
                   algorithmic 2*M*N*K per launch / mean launch duration of those launches during the timed
@@ -25,7 +32,7 @@ Extra objects on the line:
                   against 88.7 us in the rocprofv3 trace of the same run; with the stamps 84.7 against 86.6,
                   the difference being the dispatch latency rocprof counts: profiles/r03_trace_vs_stamps.txt),
                   and 24 such packets per step also cost the step itself 2 %.  The kernel evaluates every
-                  fp32-equivalent product with THREE v_mfma_f32_32x32x16_f16 (split-f16, gemm16s.hip), so
+                  fp32-equivalent product with THREE v_mfma_f32_16x16x32_f16 (split-f16, gemm16s.hip), so
                   its MFMA roofline in algorithmic (fp32-equivalent) FLOP/s is the dense f16 peak / 3.
   cpu_baseline  — the oracle (oracle/cpu_ref.py, same ATen op sequence as the reference) timed on
                   this host's cores, rank 0 at N=1 only, on a bounded sample of the same workload
@@ -75,6 +82,19 @@ def cpu_baseline(arch_name, sd, clips_np, clip_seconds):
     ncpu = os.cpu_count() or 1
     deadline = time.time() + 150.0
 
+    def cpu_model():
+        try:
+            with open("/proc/cpuinfo") as f:
+                for ln in f:
+                    if ln.startswith("model name"):
+                        return ln.split(":", 1)[1].strip()
+        except OSError:
+            pass
+        import platform
+        return platform.processor() or "unknown"
+
+    spread = {}
+
     def rate(B, reps, warm=3):
         x = torch.from_numpy(clips_np[:B])
         ts = []
@@ -91,6 +111,9 @@ def cpu_baseline(arch_name, sd, clips_np, clip_seconds):
                 ts.append(time.perf_counter() - t0)
                 if time.time() > deadline and len(ts) >= 3:
                     break
+        q = sorted(ts)
+        spread[(B, torch.get_num_threads())] = {"p10_ms": round(1e3 * q[int(0.1 * (len(q) - 1))], 2), "p50_ms": round(1e3 * statistics.median(q), 2),
+                                                "p90_ms": round(1e3 * q[int(round(0.9 * (len(q) - 1)))], 2)}
         return B * clip_seconds / statistics.median(ts), len(ts)
 
     tried = {}
@@ -102,16 +125,16 @@ def cpu_baseline(arch_name, sd, clips_np, clip_seconds):
     torch.set_num_threads(best_nt)
     for B in sorted({1, min(16, len(clips_np)), min(64, len(clips_np))}):
         r, n = rate(B, 10)
-        rows[f"B={B},threads={best_nt}"] = {"audio_s_per_s": round(r, 2), "round_trips": n}
+        rows[f"B={B},threads={best_nt}"] = {"audio_s_per_s": round(r, 2), "round_trips": n, **spread[(B, best_nt)]}
     if best_nt != min(8, ncpu):
         torch.set_num_threads(min(8, ncpu))
         for B in sorted({1, min(16, len(clips_np))}):
             r, n = rate(B, 10)
-            rows[f"B={B},threads={min(8, ncpu)}"] = {"audio_s_per_s": round(r, 2), "round_trips": n}
+            rows[f"B={B},threads={min(8, ncpu)}"] = {"audio_s_per_s": round(r, 2), "round_trips": n, **spread[(B, min(8, ncpu))]}
     torch.set_num_threads(best_nt)
     value = max(v["audio_s_per_s"] for k, v in rows.items() if k.endswith(f"threads={best_nt}"))
-    return {"value": round(value, 2), "unit": "audio-s/s", "cores": best_nt, "kind": "port",
-            "rows": rows,
+    return {"value": round(value, 2), "unit": "audio-s/s", "cores": best_nt, "kind": "port", "cpu_model": cpu_model(),
+            "logical_cpus": ncpu, "rows": rows,
             "sample": "oracle/cpu_ref.py (the reference's ATen op sequence, fp32), encode_infer+decode round trips of %d s clips: "
                       "3 warm-ups then the median of up to 10 per row; thread sweep on B=16 (2 reps): %s; value = the fastest row at "
                       "%d threads; host has %d logical CPUs"
@@ -161,8 +184,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--lanes", type=int, default=1, help="N = 1 only: steps in flight on separate HIP streams (StepRunner(lanes=...)); "
-                    "the default line times one step after the other and reports the two-lane rate in other_configs")
+    ap.add_argument("--lanes", type=int, default=2, help="N = 1 only: steps in flight on separate HIP streams (StepRunner(lanes=...)); "
+                    "default 2 (config.lanes says so); the one-stream schedule is always measured too (config.one_lane) and "
+                    "carries the roofline launch timing; --lanes 1 makes it the headline")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="N = 1: create a world-1 RCCL process group and run the end-of-step exchange (all_gather_into_tensor + "
+                         "gather, async) inside the timed steps anyway: exercises library load, stream semantics and the "
+                         "interplay with the persistent LSTM on the one GPU a development box has")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured path); gloo only rehearses the N>1 flow on a box with "
                          "fewer GPUs than ranks (ranks share GPUs, collectives go through host memory)")
@@ -182,9 +210,11 @@ def main():
     dev = torch.device("cuda", local_rank % max(1, ndev))
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_collectives:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -243,12 +273,23 @@ def main():
     wav = torch.from_numpy(clips_np).to(dev)
     bw = torch.tensor([0])
     L = arch.frames(T)
-    runner = Runner(model, wav, bw, dist, world, rank, not args.no_gather, args.backend, lanes=args.lanes if world == 1 else 1)
+    forced = args.force_collectives and world == 1
+    lanes = args.lanes if (world == 1 and not forced) else 1
+    # one stream first: the schedule the roofline launch is timed in (and the headline with --lanes 1 / N > 1)
+    runner = Runner(model, wav, bw, dist, world, rank, not args.no_gather, args.backend, lanes=1, force_collectives=forced)
     runner.step()                                                  # creates the plans
     runner.drain()
-    dplan = next(p for k, (p, _w) in model._engine.plans.items() if k[:4] == (_capi.WT_PLAN_DECODE, B, L, model._graph_flags(B)))
+    dplan = next(p for k, (p, _w) in model._engine.plans.items() if k == (_capi.WT_PLAN_DECODE, B, L, model._graph_flags(B)))
     blocks, kern = run_blocks(runner, args.steps, max(0, args.warmup - 1), args.repeats, (dplan, b"cnx.pwconv1" if os.environ.get("WT_BENCH_TIMING") == "events" else b"@cnx.pwconv1"))     # (events: tools/trace_vs_events.sh only)
     model.check_status()
+    one_lane_blocks = sorted(1e3 * b / args.steps for b in blocks)
+    if lanes > 1:
+        runner = Runner(model, wav, bw, None, 1, 0, False, args.backend, lanes=lanes)
+        for _ in range(lanes):
+            runner.step()
+        runner.drain()
+        blocks, _ = run_blocks(runner, args.steps, max(lanes, args.warmup), args.repeats)
+        model.check_status()
     own_blocks = list(runner.own_blocks)
 
     # N > 1: what every rank saw, so that the first run on a real multi-GPU node explains itself (rank 0 prints it)
@@ -260,7 +301,7 @@ def main():
                 "exchange_wait_ms_per_step": round(1e3 * runner.wait_s / max(1, runner.exchanges), 3),
                 "exchanges": runner.exchanges,
                 # (a lost co-residency would have raised in check_status() above)
-                "persistent_lstm": not (getattr(model, "_plan_flags", 0) & _capi.WT_PLAN_FLAG_STEP_LSTM)}
+                "persistent_lstm": bool(model.persistent_lstm)}      # the library's own word (a lost co-residency clears it)
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
         ranks_info = gathered
@@ -291,7 +332,7 @@ def main():
             "metric": "audio-seconds/sec encode+decode, 24 kHz %d s clips" % clip_s,
             "value": round(value, 1), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (split-f16 x3 products)",
             "dtype_note": "fp32 accumulation everywhere; residual streams, norm / LSTM-cell arithmetic and outputs are fp32; every operand of a "
                           "dense layer is STORED between layers as a split pair of f16 numbers (S32: x = hi + lo * 2^-11, 22 significant "
                           "bits, f16 exponent range guarded by a status word) and each product is formed by 3 f16 MFMAs; the same workload "
@@ -310,6 +351,16 @@ def main():
                        "weights": "random-init (synth seed 0)", "model_load_s": round(load_s, 2),
                        "hbm_weight_bytes": int(_capi.lib.wt_model_weight_bytes(model._engine.model)),
                        "parallelism": f"clips sharded dp{world}", "lanes": runner.lanes,
+                       "schedule": ("the K steps of a block are issued alternately on %d HIP streams (step i+1's encode_infer beside step i's decode); "
+                                    "each step is one full encode_infer + decode of the batch; all K complete inside the timed bracket" % runner.lanes)
+                                   if runner.lanes > 1 else "one step after the other on one HIP stream",
+                       "one_lane": {"ms_per_step": round(statistics.median(one_lane_blocks), 3), "ms_per_step_blocks": [round(x, 3) for x in one_lane_blocks],
+                                    "audio_s_per_s": round(world * B * clip_s / (statistics.median(one_lane_blocks) * 1e-3), 1),
+                                    "what": "the same workload, one step after the other on one stream (the r01-r03 headline schedule); "
+                                            "the roofline launch is timed in this block"},
+                       "persistent_lstm": bool(model.persistent_lstm),
+                       **({"forced_collectives": "world-1 RCCL process group: codes all_gather_into_tensor + waveform gather (async_op) "
+                                                 "inside every timed step"} if forced else {}),
                        **({"ranks": ranks_info} if ranks_info is not None else {}),
                        "gather": ("codes all_gather + waveform gather to rank 0 (%s), asynchronous: step i's exchange runs beside step i+1's decode "
                                   "(never beside the persistent LSTM), all finished inside the timed region" % ("RCCL" if args.backend == "nccl" else "gloo rehearsal"))
@@ -324,8 +375,8 @@ def main():
                          "algorithmic_bytes_per_launch": 4 * (Mrows * arch.dim + arch.intermediate_dim * arch.dim + Mrows * arch.intermediate_dim),
                          "flops_per_launch": flops, "avg_launch_ms": round(kern_ms, 4), "launches_timed": kern[1],
                          "launch_timing": "device clock (s_memrealtime, 100 MHz) of the launch's first workgroup entry to its last exit, every "
-                                          "pwconv1 launch of the timed steps; no events in the stream (profiles/r03_trace_vs_stamps.txt compares it "
-                                          "with the rocprofv3 trace and with bracketing HIP events in one run)",
+                                          "pwconv1 launch of the timed ONE-LANE steps (config.one_lane); no events in the stream "
+                                          "(profiles/r03_trace_vs_stamps.txt compares it with the rocprofv3 trace and with bracketing HIP events in one run)",
                          "end_to_end_tflops": round(e2e_tflops, 2),
                          "end_to_end_frac": round(e2e_tflops / PEAK_F16X3_TFLOPS, 4)},
         }
@@ -402,21 +453,89 @@ def main():
             "steps": 5, "blocks": 3}
         del r32
 
-        # the headline workload with two steps in flight: step i+1's encode_infer on a second HIP stream beside step i's decode
-        # (StepRunner(lanes=2): one plan + workspace per stream, the persistent LSTM launches of the two streams chained by the
-        # library).  Same kernels and results; the second stream fills launch gaps and the partly idle last round of each GEMM
-        r2 = Runner(model, wav, bw, None, 1, 0, False, args.backend, lanes=2)
-        r2.step(); r2.step(); r2.drain()
-        blk, _ = run_blocks(r2, args.steps, 2, 3)
-        ms2 = statistics.median(1e3 * t / args.steps for t in blk)
-        model.check_status()
-        other["two_lane_pipeline_64x3s"] = {
-            "what": "configs[1], steps issued alternately on two HIP streams (sharding.StepRunner(lanes=2)); not the headline: "
-                    "the headline times one step after the other on one stream",
-            "ms_per_step": round(ms2, 3), "audio_s_per_s": round(B * clip_s / (ms2 * 1e-3), 1),
-            "vs_one_stream": round(line["ms_per_step"] / ms2, 4), "steps": args.steps, "blocks": 3}
-        del r2
-        model._engine.drop(lambda k: len(k) == 5)
+        # the host-resident pipeline ("H2D reported separately"; the reference's script reads and writes files:
+        # infer.py:44-70): pinned host buffers -> H2D on a copy stream -> encode_infer + decode + PCM16 on two lanes -> D2H of
+        # the int16 samples on a second copy stream, double-buffered (sharding.HostPipeline)
+        try:
+            from wavtokenizer_amd.sharding import HostPipeline
+            hp = HostPipeline(model, B, T, bw, lanes=2)
+            for k in range(hp.lanes):
+                hp.h_in[k].copy_(torch.from_numpy(clips_np))
+            for _ in range(4):
+                hp.step()
+            hp.drain()
+            blk = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    hp.step()
+                hp.drain()
+                blk.append(1e3 * (time.perf_counter() - t0) / args.steps)
+            for _ in range(6):                      # the copies alone, timed on their streams (events would sit between the kernels otherwise)
+                hp.step(time_copies=True)
+            hp.drain()
+            h2d_ms, d2h_ms = hp.copy_times_ms()
+            model.check_status()
+            ms_hp = statistics.median(blk)
+            resident = line["ms_per_step"]
+            pcm = hp.h_out[0].numpy()
+            other["host_pipeline_64x3s"] = {
+                "what": "configs[1] from and to HOST memory: pinned fp32 waveforms -> H2D (copy stream) -> encode_infer + decode + "
+                        "PCM16 (wt_pcm16) on two lanes -> D2H of int16 samples (second copy stream), double-buffered; infer.py:44-70",
+                "ms_per_step": round(ms_hp, 3), "audio_s_per_s": round(B * clip_s / (ms_hp * 1e-3), 1), "ms_per_step_blocks": [round(x, 3) for x in sorted(blk)],
+                "h2d_ms_per_step": round(h2d_ms, 3), "h2d_bytes": int(B * T * 4), "h2d_GBps": round(B * T * 4 / (h2d_ms * 1e-3) / 1e9, 1),
+                "d2h_ms_per_step": round(d2h_ms, 3), "d2h_bytes": int(pcm.size * 2), "d2h_GBps": round(pcm.size * 2 / (d2h_ms * 1e-3) / 1e9, 1),
+                "fraction_of_resident_rate": round(resident / ms_hp, 4),
+                "bound": "compute (the copies of step i run beside the kernels of steps i-1 / i+1)" if ms_hp < 1.1 * resident else
+                         "see the copy times: the step is longer than the resident-input step by more than 10 %",
+                "pcm16_nonzero": bool((pcm != 0).any()), "steps": args.steps, "blocks": 3}
+            del hp
+        except Exception as e:                      # a measurement row must not cost the headline line
+            other["host_pipeline_64x3s"] = {"error": repr(e)[:300]}
+        model._engine.drop(lambda k: len(k) >= 5 and k[4])
+
+        # RCCL on the one GPU there is: a world-1 nccl process group with device_id, the exchange of
+        # StepRunner(gather=True) - codes all_gather_into_tensor + waveform gather, async_op - for 20 steps beside the
+        # persistent LSTM; the exchange order is asserted on the REAL codec's log and the gathered tensors against the step's own
+        try:
+            import torch.distributed as tdist
+            from wavtokenizer_amd.sharding import check_exchange_order
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+            own_pg = not tdist.is_initialized()
+            if own_pg:
+                tdist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            log = []
+            rr = Runner(model, wav, bw, tdist, 1, 0, True, "nccl", log=log, force_collectives=True)
+            n_st = 20
+            ok = True
+            prev = None
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n_st):
+                codes_i, out_i, res = rr.step()
+                if res is not None and prev is not None:
+                    ok = ok and torch.equal(res[0], prev[0]) and torch.equal(res[1], prev[1])
+                prev = (codes_i, out_i)
+            res = rr.drain()
+            ok = ok and res is not None and torch.equal(res[0], prev[0]) and torch.equal(res[1], prev[1])
+            torch.cuda.synchronize()
+            ms_rc = 1e3 * (time.perf_counter() - t0) / n_st
+            check_exchange_order(log, n_st)
+            model.check_status()                    # an RCCL kernel in flight must not have tripped WT_STATUS_LSTM
+            other["rccl_world1"] = {
+                "what": "world-1 RCCL process group (device_id set): StepRunner(gather=True, force_collectives=True), 20 steps; codes "
+                        "all_gather_into_tensor + waveform gather(async_op=True) issued behind step i+1's encode_infer, collected before "
+                        "the step returns",
+                "backend": tdist.get_backend(), "world_size": tdist.get_world_size(), "steps": n_st, "ms_per_step": round(ms_rc, 3),
+                "exchanges": rr.exchanges, "exchange_wait_ms_per_step": round(1e3 * rr.wait_s / max(1, rr.exchanges), 3),
+                "exchange_order_ok": True, "gathered_equals_own": bool(ok), "persistent_lstm_after": bool(model.persistent_lstm),
+                "ranks": [{"rank": 0, "device": torch.cuda.get_device_name(dev), "device_index": dev.index}]}
+            if own_pg:
+                tdist.destroy_process_group()
+        except Exception as e:
+            other["rccl_world1"] = {"error": repr(e)[:300]}
 
         # BASELINE configs[4], per-GPU share: hop-600, 32 clips x 30 s
         wav30 = torch.from_numpy(synth.make_clips(32, 30 * SAMPLE_RATE, seed=1000 * 4)).to(dev)

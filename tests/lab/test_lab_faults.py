@@ -143,6 +143,7 @@ def test_graph_replays_resume_after_the_lstm_fallback(gpu_model):
     finally:
         m.set_lstm_mode("persistent")
     m._engine.drop(lambda k: True)
+    m.set_strict_status(False)          # (the default for two clips is strict: the failed call would be repeated at once)
     os.environ["WT_LSTM_PERSIST_FAULT"] = "1"
     try:
         f1, c1 = m.encode_infer(wav, bandwidth_id=BW)          # eager first call of a new plan: the forced fault
@@ -160,4 +161,30 @@ def test_graph_replays_resume_after_the_lstm_fallback(gpu_model):
     assert replays[-1] >= 5 and replays[-1] > replays[2], f"the recorded graph is not being replayed after the fallback: {replays}"
     assert not _capi.lib.wt_model_persistent_lstm(m._engine.model)
     with pytest.raises(_capi.WavTokError, match="fallback"):
+        m.check_status()
+
+
+def test_small_batches_never_hand_out_poisoned_tensors_by_default(gpu_model):
+    """VERDICT r03 #3c: with the default (automatic) strict status an infer.py-style caller (one clip per call) gets the
+    CORRECT result from the very call whose persistent LSTM failed: the class synchronises, sees the status bit, falls back
+    and repeats the call before returning."""
+    import os
+    from wavtokenizer_amd import synth
+    name, _m, sd = gpu_model
+    m = _fresh_model(name, sd)
+    wav = torch.from_numpy(synth.make_clips(1, 9100, seed=734)).cuda()
+    m.set_lstm_mode("step")
+    try:
+        f_ref, c_ref = m.encode_infer(wav, bandwidth_id=BW)
+    finally:
+        m.set_lstm_mode("persistent")
+    m._engine.drop(lambda k: True)
+    os.environ["WT_LSTM_PERSIST_FAULT"] = "1"
+    try:
+        f1, c1 = m.encode_infer(wav, bandwidth_id=BW)
+    finally:
+        del os.environ["WT_LSTM_PERSIST_FAULT"]
+    assert torch.equal(c1, c_ref) and torch.equal(f1, f_ref)
+    assert not m.persistent_lstm
+    with pytest.raises(Exception, match="fallback"):
         m.check_status()

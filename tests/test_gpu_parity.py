@@ -1388,3 +1388,48 @@ def test_fault_injection_on_the_lab_library():
     tail = (r.stdout or "")[-3000:] + (r.stderr or "")[-1500:]
     assert r.returncode == 0, tail
     assert " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], tail
+
+
+def test_rccl_world1_exchange_beside_the_persistent_lstm():
+    """the `nccl` branch had never executed anywhere.  On the one GPU of this box: a world-1 RCCL process group
+    (device_id set), StepRunner(gather=True, force_collectives=True) for 20 steps of 8 clips beside the persistent LSTM;
+    asserts the exchange order on the real codec's log, the gathered tensors against the steps' own, no
+    status bit (an RCCL kernel in flight must not cost the persistent LSTM its co-residency), persistent LSTM still on."""
+    import os
+    import torch.distributed as dist
+    from wavtokenizer_amd import synth
+    from wavtokenizer_amd.sharding import StepRunner, check_exchange_order
+    from tests import parity_log
+    name = "hop600"
+    m, _sd = _model(name)
+    m.set_graph_max_clips(0)                   # direct launches: the persistent kernel itself, not a replayed graph
+    dev = torch.device("cuda", torch.cuda.current_device())
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 2000))
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        wav = torch.from_numpy(synth.make_clips(8, 24000, seed=911)).cuda()
+        f0, c0 = m.encode_infer(wav, bandwidth_id=BW)
+        w0 = m.decode(f0, bandwidth_id=BW)
+        log = []
+        r = StepRunner(m, wav, BW, dist, 1, 0, gather=True, backend="nccl", log=log, force_collectives=True)
+        assert r.gather
+        prev = None
+        for i in range(20):
+            codes, out, res = r.step()
+            assert torch.equal(codes, c0) and torch.equal(out, w0)
+            if prev is not None:
+                assert res is not None and torch.equal(res[0], prev[0]) and torch.equal(res[1], prev[1])
+            prev = (codes, out)
+        res = r.drain()
+        assert torch.equal(res[0], prev[0]) and torch.equal(res[1], prev[1])
+        torch.cuda.synchronize()
+        check_exchange_order(log, 20)
+        m.check_status()
+        assert m.persistent_lstm and r.exchanges == 20
+        parity_log.record("rccl_world1", exchanges=r.exchanges, backend=dist.get_backend(), exchange_wait_ms=1e3 * r.wait_s / r.exchanges)
+    finally:
+        if own:
+            dist.destroy_process_group()

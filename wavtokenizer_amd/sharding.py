@@ -83,7 +83,7 @@ class PendingGather:
 
 
 def gather_async(codes_local: torch.Tensor, wav_local: torch.Tensor, dist, world: int, rank: int, dst: int = 0,
-                 counts: Optional[List[int]] = None) -> PendingGather:
+                 counts: Optional[List[int]] = None) -> "PendingGather":
     """Non-blocking form of gather_codes + gather_waveforms: both collectives are issued with async_op=True, so on
     RCCL they overlap the kernels the caller enqueues next; the buffers stay referenced by the returned object."""
     K, b, L = codes_local.shape
@@ -122,10 +122,14 @@ class StepRunner:
     (wavtokenizer_amd/csrc/lstm_persist.hip).  `log`, when given, receives (event, step) tuples in host order:
     "encode", "issue", "decode", "collect" - the tests assert the invariant on it."""
 
-    def __init__(self, model, wav, bw, dist, world, rank, gather=True, backend="nccl", dst=0, log=None, lanes=1):
+    def __init__(self, model, wav, bw, dist, world, rank, gather=True, backend="nccl", dst=0, log=None, lanes=1,
+                 force_collectives=False):
         self.model, self.wav, self.bw = model, wav, bw
         self.dist, self.world, self.rank, self.backend, self.dst = dist, world, rank, backend, dst
-        self.gather = bool(gather) and world > 1
+        # force_collectives: run the exchange in a world of ONE rank too (bench.py --force-collectives, the rccl_world1 row and
+        # test): the RCCL calls, their stream semantics and their interplay with the persistent LSTM are then exercised on the
+        # single GPU a development box has
+        self.gather = bool(gather) and (world > 1 or (force_collectives and dist is not None))
         # lanes > 1 (only without the exchange): step i runs on HIP stream i % lanes, so step i+1's encode_infer runs beside
         # step i's decode and fills the launch gaps and last-round tails of its kernels.  The model keeps a plan + workspace
         # per stream (pretrained._Engine._key) and the library chains the persistent LSTM launches of different streams
@@ -211,3 +215,95 @@ def check_exchange_order(log, n_steps):
                 assert pos[("collect", i)] < pos[("encode", i + 2)]
         else:
             assert pos[("decode", i)] < pos[("issue", i)] < pos[("collect", i)]      # the drain
+
+
+class HostPipeline:
+    """The round trip as the reference's own script runs it (infer.py:44-70: waveform in host memory -> encode_infer ->
+    decode -> 16-bit PCM back in host memory), for batches, with the host <-> device legs overlapped with compute:
+
+        H2D stream : pinned host waveforms (B, T) fp32 -> device                      (18.4 MB at 64 x 3 s)
+        lane k     : encode_infer + decode + the PCM16 conversion (wt_pcm16) on its own HIP stream
+        D2H stream : int16 samples -> pinned host buffer                              (9.2 MB: half the fp32 bytes)
+
+    Step i uses lane i % lanes; a lane's device and host buffers are reused every `lanes` steps, ordered by events (the H2D
+    of step i + lanes waits for step i's encode to have read the input, its PCM conversion for step i's D2H to have left).
+    The two copy directions have a stream each (PCIe is full duplex).  `h2d_ms` / `d2h_ms` are the summed device times of
+    the copies (events on the copy streams), reported separately as SURVEY 8(d) asks."""
+
+    def __init__(self, model, B: int, T: int, bw, lanes: int = 2, device=None, limit: float = 0.99):
+        import ctypes
+        from . import _capi
+        self._ctypes, self._capi = ctypes, _capi
+        self.model, self.bw, self.B, self.T, self.lanes, self.limit = model, bw, B, T, int(lanes), float(limit)
+        dev = torch.device(device) if device is not None else model._device()
+        self.dev = dev
+        L = model.arch.frames(T)
+        self.n_out = model._wave_len(L)
+        self.h_in = [torch.empty((B, T), dtype=torch.float32).pin_memory() for _ in range(self.lanes)]
+        self.h_out = [torch.empty((B, self.n_out), dtype=torch.int16).pin_memory() for _ in range(self.lanes)]
+        self.d_in = [torch.empty((B, T), dtype=torch.float32, device=dev) for _ in range(self.lanes)]
+        self.d_pcm = [torch.empty((B, self.n_out), dtype=torch.int16, device=dev) for _ in range(self.lanes)]
+        self.d_ws = [torch.zeros(4, dtype=torch.int32, device=dev) for _ in range(self.lanes)]
+        self.s_h2d, self.s_d2h = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        self.s_lane = [torch.cuda.Stream(device=dev) for _ in range(self.lanes)]
+        self.e_in = [torch.cuda.Event() for _ in range(self.lanes)]          # H2D of the lane's current step done
+        self.e_read = [None] * self.lanes                                      # the lane's encode has consumed its input
+        self.e_pcm = [torch.cuda.Event() for _ in range(self.lanes)]         # PCM16 of the lane's current step written
+        self.e_out = [None] * self.lanes                                       # D2H of the lane's previous step done
+        self.i = 0
+        self.codes = [None] * self.lanes
+        self.timed = []                                                        # (h2d start, h2d end, d2h start, d2h end) events
+
+    def step(self, time_copies: bool = False):
+        ct, capi = self._ctypes, self._capi
+        k = self.i % self.lanes
+        self.i += 1
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if time_copies else None
+        with torch.cuda.stream(self.s_h2d):
+            if self.e_read[k] is not None:
+                self.s_h2d.wait_event(self.e_read[k])                          # the previous step of this lane has read d_in[k]
+            if ev:
+                ev[0].record()
+            self.d_in[k].copy_(self.h_in[k], non_blocking=True)
+            if ev:
+                ev[1].record()
+            self.e_in[k].record()
+        st = self.s_lane[k]
+        with torch.cuda.stream(st):
+            st.wait_event(self.e_in[k])
+            feats, codes = self.model.encode_infer(self.d_in[k], bandwidth_id=self.bw)
+            self.e_read[k] = torch.cuda.Event()
+            self.e_read[k].record()
+            out = self.model.decode(feats, bandwidth_id=self.bw)
+            if self.e_out[k] is not None:
+                st.wait_event(self.e_out[k])                                   # d_pcm[k] of the previous step has left
+            capi.check(capi.lib.wt_pcm16(ct.c_void_p(out.data_ptr()), out.numel(), self.limit, 0, ct.c_void_p(self.d_pcm[k].data_ptr()),
+                                         ct.c_void_p(self.d_ws[k].data_ptr()), ct.c_void_p(st.cuda_stream)), "wt_pcm16")
+            self.e_pcm[k].record()
+            self.codes[k] = codes
+        with torch.cuda.stream(self.s_d2h):
+            self.s_d2h.wait_event(self.e_pcm[k])
+            if ev:
+                ev[2].record()
+            self.h_out[k].copy_(self.d_pcm[k], non_blocking=True)
+            if ev:
+                ev[3].record()
+            self.e_out[k] = torch.cuda.Event()
+            self.e_out[k].record()
+        if ev:
+            self.timed.append(ev)
+        return k
+
+    def drain(self):
+        """Everything submitted so far is in host memory when this returns."""
+        for s in (self.s_h2d, self.s_d2h, *self.s_lane):
+            s.synchronize()
+
+    def copy_times_ms(self):
+        """(h2d ms per step, d2h ms per step) over the steps made with time_copies=True (call after drain())."""
+        if not self.timed:
+            return None, None
+        h = sum(e[0].elapsed_time(e[1]) for e in self.timed) / len(self.timed)
+        d = sum(e[2].elapsed_time(e[3]) for e in self.timed) / len(self.timed)
+        self.timed = []
+        return h, d
