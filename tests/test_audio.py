@@ -116,3 +116,42 @@ def test_segmented_round_trip():
         err = rel_l2(got.cpu().numpy(), want)
         parity_log.record(f"segmented_round_trip[{seg_len},{stride}]", wav_rel_l2=err)
         assert err < WAV_REL_TOL, (seg_len, stride, err)
+
+
+@pytest.mark.gpu
+def test_host_pipeline_matches_the_resident_round_trip():
+    """sharding.HostPipeline (infer.py:44-70 for batches: pinned host waveforms -> H2D -> encode_infer + decode + PCM16 -> D2H,
+    two lanes): the int16 samples that arrive in host memory equal to_pcm16(decode(encode_infer(wav))) computed the plain way,
+    for every step of a run that reuses each lane's buffers several times."""
+    import numpy as np
+    import torch
+    from wavtokenizer_amd import WavTokenizer, NAMED_ARCHS, synth, audio
+    from wavtokenizer_amd.sharding import HostPipeline
+    from tests.util import synth_state_dict
+    arch = NAMED_ARCHS["hop600"]
+    m = WavTokenizer.from_arch(arch)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict("hop600").items()}, strict=False)
+    m = m.eval().to("cuda")
+    bw = torch.tensor([0])
+    B, T = 4, 24000
+    hp = HostPipeline(m, B, T, bw, lanes=2)
+    got, want = [], []
+    for i in range(6):
+        wav = synth.make_clips(B, T, seed=800 + i)
+        k = i % hp.lanes
+        hp.s_lane[k].synchronize()                   # the lane's previous step has left its host buffers
+        if i >= hp.lanes:
+            got.append(hp.h_out[k].numpy().copy())
+        hp.h_in[k].copy_(torch.from_numpy(wav))
+        hp.step()
+        f, _c = m.encode_infer(torch.from_numpy(wav).cuda(), bandwidth_id=bw)
+        want.append(audio.to_pcm16(m.decode(f, bandwidth_id=bw)).cpu().numpy())
+    hp.drain()
+    got.append(hp.h_out[0].numpy().copy())
+    got.append(hp.h_out[1].numpy().copy())
+    assert len(got) == len(want) == 6
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g.dtype == np.int16 and np.array_equal(g, w), i
+    h2d, d2h = hp.copy_times_ms(2)
+    assert h2d > 0 and d2h > 0
+    m.check_status()

@@ -760,6 +760,86 @@ int packed_verify(const void* buf, size_t n) {
     return WT_OK;
 }
 
+// The model section of a packed image is data from a file: after archive_model every dimension is recomputed from the
+// header's wt_arch (what build_model would have set) and compared, and every pointer's EXTENT - not only its start - must lie
+// inside the allocation it points into.  The body hash only detects accidental corruption (it is not cryptographic): a
+// crafted file must not be able to make a plan size its launches past an allocation.
+static int validate_imported(const wt_model* M) {
+    const wt_arch& a = M->arch;
+    auto fits = [&](const void* p, size_t bytes) {
+        if (!p) return false;
+        const char* c = static_cast<const char*>(p);
+        for (size_t i = 0; i < M->allocs.size(); ++i) {
+            const char* base = static_cast<const char*>(M->allocs[i]);
+            if (c >= base && c < base + M->alloc_bytes[i]) return bytes <= (size_t)(base + M->alloc_bytes[i] - c);
+        }
+        return false;
+    };
+    auto bad = [](const char* what) { set_error(std::string("packed image: ") + what + " does not match the architecture in its header"); return WT_ERR_INVALID; };
+    auto conv_ok = [&](const ConvW& c, int cout, int cin, int k) {
+        return c.cout == cout && c.cin == cin && c.k == k && fits(c.w, (size_t)cout * cin * k * 4) && fits(c.b, (size_t)cout * 4);
+    };
+    auto lstm_ok = [&](const LstmW& l, int H) {
+        const size_t hh = (size_t)4 * H * H * 4;
+        return fits(l.Wih0, hh) && fits(l.b0, (size_t)16 * H) && fits(l.W0, hh) && fits(l.W1, 2 * hh) && fits(l.b1, (size_t)16 * H) &&
+               (!l.W0h || fits(l.W0h, hh)) && (!l.W1h || fits(l.W1h, 2 * hh)) &&
+               (!l.Wp || fits(l.Wp, (size_t)3 * 32 * 4 * 16 * 2 * 64 * 16));
+    };
+    const int nf = 32, H = 512, D = a.dim, I = a.intermediate_dim;
+    if (a.n_ratios < 1 || a.n_ratios > 8 || a.num_quantizers != 1 || a.input_channels != 512 || D % 256 || I % 32 || a.num_layers < 1 || a.num_layers > 32 ||
+        a.adanorm_num_embeddings < 1 || a.vq_bins < 1 || a.n_fft < 4 || a.hop_length < 1) return bad("the architecture itself");
+    int hop = 1;
+    for (int i = 0; i < a.n_ratios; ++i) { if (a.ratios[i] < 1 || a.ratios[i] > 64) return bad("a ratio"); hop *= a.ratios[i]; }
+    if (M->hop != hop || M->H != H || (int)M->enc_ratios.size() != a.n_ratios || (int)M->stages.size() != a.n_ratios) return bad("the encoder's shape");
+    if (M->e0_k != 7 || M->e0_c != nf || !fits(M->e0_w, 7 * nf * 4) || !fits(M->e0_b, nf * 4)) return bad("the first conv");
+    int mult = 1;
+    for (int i = 0; i < a.n_ratios; ++i) {
+        const ResStage& st = M->stages[i];
+        const int r = a.ratios[a.n_ratios - 1 - i], C = mult * nf;
+        if (M->enc_ratios[i] != r || st.C != C || st.r != r || !conv_ok(st.c3, C / 2, C, 3) || !conv_ok(st.c1, C, C / 2, 1) || !conv_ok(st.sc, C, C, 1) ||
+            !conv_ok(st.down, 2 * C, C, 2 * r)) return bad("an encoder stage");
+        if (st.cat.w && !(st.cat.cout == C && st.cat.cin == C + C / 2 && st.cat.k == 1 && fits(st.cat.w, (size_t)C * (C + C / 2) * 4) && fits(st.cat.b, (size_t)C * 4)))
+            return bad("a fused shortcut weight");
+        mult *= 2;
+    }
+    if (mult * nf != H || !lstm_ok(M->enc_lstm, H) || !conv_ok(M->enc_final, 512, H, 7)) return bad("the encoder tail");
+    if (!fits(M->embed, (size_t)a.vq_bins * 512 * 4) || !fits(M->ee, (size_t)a.vq_bins * 4)) return bad("the codebook");
+    if (!conv_ok(M->bb_embed, D, 512, 7)) return bad("backbone.embed");
+    for (const PosRes& r : M->res)
+        if (!fits(r.n1w, D * 4) || !fits(r.n1b, D * 4) || !fits(r.n2w, D * 4) || !fits(r.n2b, D * 4) || !conv_ok(r.c1, D, D, 3) || !conv_ok(r.c2, D, D, 3)) return bad("a pos_net block");
+    if (!fits(M->at_nw, D * 4) || !fits(M->at_nb, D * 4) || !fits(M->at_Wqk, (size_t)2 * D * D * 4) || !fits(M->at_bqk, 2 * D * 4) || !fits(M->at_Wv, (size_t)D * D * 4) ||
+        !fits(M->at_bv, D * 4) || !fits(M->at_Wp, (size_t)D * D * 4) || !fits(M->at_bp, D * 4)) return bad("the attention block");
+    const size_t ada = (size_t)a.adanorm_num_embeddings * D * 4;
+    if (!fits(M->gn5w, D * 4) || !fits(M->gn5b, D * 4) || !fits(M->ada_s, ada) || !fits(M->ada_h, ada)) return bad("backbone.norm");
+    if ((int)M->cnx.size() != a.num_layers) return bad("the ConvNeXt block count");
+    for (const CnxBlock& c : M->cnx)
+        if (!fits(c.dw_w, (size_t)7 * D * 4) || !fits(c.dw_b, D * 4) || !fits(c.ada_s, ada) || !fits(c.ada_h, ada) || !fits(c.W1, (size_t)I * D * 4) || !fits(c.b1, I * 4) ||
+            !fits(c.W2, (size_t)D * I * 4) || !fits(c.b2, D * 4) || !fits(c.gamma, D * 4)) return bad("a ConvNeXt block");
+    const int N = a.n_fft;
+    if (N % 4 || N % a.hop_length) return bad("n_fft / hop_length");
+    const int Kq = ((N / 4 + 1 + 31) / 32) * 32, Kb = 2 * Kq;
+    if (M->Kq != Kq || M->Kb != Kb || M->bins_f != N / 2 + 1 || M->R != N / a.hop_length) return bad("the ISTFT head's shape");
+    if (!fits(M->fln_w, D * 4) || !fits(M->fln_b, D * 4) || !fits(M->head_W, (size_t)2 * Kb * D * 4) || !fits(M->head_b, (size_t)2 * Kb * 4) ||
+        !fits(M->istft_W, (size_t)4 * Kq * Kq * 4) || !fits(M->win, (size_t)N * 4) || !fits(M->wsq, (size_t)N * 4)) return bad("the ISTFT head");
+    if (M->has_seadec) {
+        if ((int)M->sd_stages.size() != a.n_ratios || !conv_ok(M->sd_first, (1 << a.n_ratios) * nf, 512, 7) || !lstm_ok(M->sd_lstm, H)) return bad("the SEANetDecoder");
+        int m2 = 1 << a.n_ratios;
+        for (int i = 0; i < a.n_ratios; ++i) {
+            const SeaDecStage& st = M->sd_stages[i];
+            const int r = a.ratios[i], cin = m2 * nf, h = cin / 2;
+            if (st.cin != cin || st.cout != h || st.k != 2 * r || st.r != r || !fits(st.tr_w, (size_t)2 * r * cin * h * 4) || (st.tr_wp && !fits(st.tr_wp, (size_t)2 * r * cin * h * 4)) ||
+                !fits(st.tr_b, h * 4) || !conv_ok(st.c3, h / 2, h, 3) || !conv_ok(st.c1, h, h / 2, 1) || !conv_ok(st.sc, h, h, 1)) return bad("a SEANetDecoder stage");
+            if (st.cat.w && !(st.cat.cout == h && st.cat.cin == h + h / 2 && fits(st.cat.w, (size_t)h * (h + h / 2) * 4) && fits(st.cat.b, (size_t)h * 4))) return bad("a SEANetDecoder fused shortcut");
+            m2 /= 2;
+        }
+        if (!fits(M->sd_last_w, 7 * nf * 4) || !fits(M->sd_last_b, 4)) return bad("the SEANetDecoder's last conv");
+    }
+    // S32 copies: same footprint as the fp32 array they stand for; keys must be weights the plans look up (checked by extent)
+    for (const auto& kv : M->s32) if (!kv.first || !kv.second || !fits(kv.first, 128) || !fits(kv.second, 128)) return bad("an S32 copy");
+    for (const auto& kv : M->s32_acc_scale) if (!(kv.second > 0.f) || !std::isfinite(kv.second)) return bad("an S32 scale");
+    return WT_OK;
+}
+
 int model_import(wt_model* M, const void* buf, size_t n) {
     PackHeader h;
     if (int rc = packed_verify(buf, n)) return rc;
@@ -801,7 +881,7 @@ int model_import(wt_model* M, const void* buf, size_t n) {
             set_error("packed image: bad entry in the list of unstored fp32 arrays"); return WT_ERR_INVALID;
         }
     }
-    return WT_OK;
+    return validate_imported(M);
 }
 
 // The fp32 GEMM weights a packed image does not store, rebuilt from their S32 copies: w = (hi + lo * 2^-11) / scale.  Called
