@@ -182,7 +182,7 @@ class OracleWavTokenizer:
         n_bins = self.arch.vq_bins
         offsets = torch.arange(0, n_bins * len(codes), n_bins)
         idx = codes + offsets.view(-1, 1, 1)
-        tmp = torch.cat([self.sd[VQ + "embed"]], dim=0)
+        tmp = torch.cat([self.sd[VQ.replace("layers.0.", f"layers.{q}.") + "embed"] for q in range(self.arch.num_quantizers)], dim=0)
         feats = F.embedding(idx, tmp).sum(dim=0)
         return feats.transpose(1, 2)
 

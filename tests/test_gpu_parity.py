@@ -1433,3 +1433,40 @@ def test_rccl_world1_exchange_beside_the_persistent_lstm():
     finally:
         if own:
             dist.destroy_process_group()
+
+
+def test_codes_to_features_sums_several_codebooks():
+    """decoder/pretrained.py:230-237 sums the rows of K concatenated codebooks.  Every YAML of the reference has
+    num_quantizers = 1; a checkpoint with more (K <= num_quantizers codes per frame) goes through the same gather: bit-equal
+    to the oracle's F.embedding(...).sum(0) for K = 1, 2 and 3, (K, L) and (K, B, L) layouts, and encode_infer still uses the
+    first codebook alone (vq.py:137)."""
+    import dataclasses
+    from wavtokenizer_amd import WavTokenizer, NAMED_ARCHS, synth
+    from oracle.cpu_ref import OracleWavTokenizer
+    arch = dataclasses.replace(NAMED_ARCHS["hop600"], num_quantizers=3)
+    sd = synth.make_state_dict(arch, seed=manifest()["weight_seed"])
+    m = WavTokenizer.from_arch(arch)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    m = m.eval().to("cuda")
+    orc = OracleWavTokenizer(arch, sd)
+    gen = torch.Generator().manual_seed(3)
+    for K in (1, 2, 3):
+        codes = torch.randint(0, arch.vq_bins, (K, 5, 37), generator=gen)
+        assert torch.equal(m.codes_to_features(codes.cuda()).cpu(), orc.codes_to_features(codes))
+    c2 = torch.randint(0, arch.vq_bins, (2, 19), generator=gen)
+    assert torch.equal(m.codes_to_features(c2.cuda()).cpu(), orc.codes_to_features(c2))
+    import os
+    from tests.util import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "hop600_codebooks3.npz"))          # captured from the reference class itself
+    for tag in ("k1", "k2", "k3", "k2_2d"):
+        assert np.array_equal(m.codes_to_features(torch.from_numpy(g[f"{tag}/codes"]).cuda()).cpu().numpy(), g[f"{tag}/features"]), tag
+    with pytest.raises(Exception):
+        m.codes_to_features(torch.zeros(4, 1, 7, dtype=torch.int64, device="cuda"))      # more code rows than codebooks
+    # the encode path of this checkpoint equals the single-codebook model's (same layer-0 weights)
+    m1, _sd1 = _model("hop600")
+    wav = torch.from_numpy(synth.make_clips(2, 9000, seed=12)).cuda()
+    f3, c3 = m.encode_infer(wav, bandwidth_id=BW)
+    f1, c1 = m1.encode_infer(wav, bandwidth_id=BW)
+    assert c3.shape == (1, 2, 15) and torch.equal(c3, c1) and torch.equal(f3, f1)
+    assert torch.equal(m.codes_to_features(c3), f3)
+    m.check_status()

@@ -151,3 +151,30 @@ def test_istft_center_padding_fixture():
             got = orc.decode(feats, torch.tensor([0])).numpy()
         assert got.shape == want.shape == (feats.shape[0], (feats.shape[2] - 1) * arch.hop_length)
         assert np.array_equal(got, want), tag
+
+
+def test_codes_to_features_with_several_codebooks():
+    """pretrained.py:230-237 with K codebooks: offsets k * bins into the concatenated table, summed over k."""
+    import dataclasses
+    from wavtokenizer_amd import synth
+    arch = dataclasses.replace(NAMED_ARCHS["hop600"], num_quantizers=2)
+    sd = synth.make_state_dict(arch, seed=0)
+    orc = OracleWavTokenizer(arch, sd)
+    codes = torch.randint(0, arch.vq_bins, (2, 3, 11), generator=torch.Generator().manual_seed(1))
+    e0 = torch.from_numpy(sd["feature_extractor.encodec.quantizer.vq.layers.0._codebook.embed"])
+    e1 = torch.from_numpy(sd["feature_extractor.encodec.quantizer.vq.layers.1._codebook.embed"])
+    assert torch.equal(orc.codes_to_features(codes), (e0[codes[0]] + e1[codes[1]]).transpose(1, 2))
+    assert torch.equal(orc.codes_to_features(codes[:1]), e0[codes[0]].transpose(1, 2))
+
+
+def test_codes_to_features_fixture_three_codebooks():
+    """The reference's own codes_to_features on a num_quantizers = 3 model (tests/golden/make_golden_codebooks.py)."""
+    import dataclasses
+    import os
+    from wavtokenizer_amd import synth
+    from tests.util import GOLDEN
+    arch = dataclasses.replace(NAMED_ARCHS["hop600"], num_quantizers=3)
+    g = np.load(os.path.join(GOLDEN, "hop600_codebooks3.npz"))
+    orc = OracleWavTokenizer(arch, synth.make_state_dict(arch, seed=int(g["weight_seed"])))
+    for tag in ("k1", "k2", "k3", "k2_2d"):
+        assert np.array_equal(orc.codes_to_features(torch.from_numpy(g[f"{tag}/codes"])).numpy(), g[f"{tag}/features"]), tag

@@ -65,7 +65,7 @@ const char* wt_version(void) { return "wavtokenizer_amd 0.1 (gfx950, split-f16 M
 int wt_model_create(const wt_arch* arch, const wt_tensor* tensors, int32_t n_tensors, int32_t device, wt_model** out) {
     if (!arch || !tensors || !out) { set_error("wt_model_create: null argument"); return WT_ERR_INVALID; }
     if (arch->n_ratios < 1 || arch->n_ratios > 8) { set_error("n_ratios out of range"); return WT_ERR_INVALID; }
-    if (arch->num_quantizers != 1) { set_error("only num_quantizers=1 is implemented (vq.py:137 forces n_q=1 at inference)"); return WT_ERR_INVALID; }
+    if (arch->num_quantizers < 1 || arch->num_quantizers > 32) { set_error("num_quantizers must be 1 .. 32 (encode_infer uses the first codebook: vq.py:137 forces n_q = 1; codes_to_features sums up to num_quantizers of them)"); return WT_ERR_INVALID; }
     if (arch->input_channels != 512) { set_error("input_channels must be 512 (SEANet dimension)"); return WT_ERR_INVALID; }
     if (arch->dim % 256 || arch->intermediate_dim % 32) { set_error("dim must be a multiple of 256, intermediate_dim of 32"); return WT_ERR_INVALID; }
     if (arch->dim % 32 || (arch->dim / 32) % 4) { set_error("dim/32 (GroupNorm group width) must be a multiple of 4"); return WT_ERR_INVALID; }

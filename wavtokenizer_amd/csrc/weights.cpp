@@ -222,7 +222,19 @@ int build_model(wt_model* M, TensorMap& tm) {
             set_error("codebook buffer `inited` is not 1: the reference would run k-means on the first forward (core_vq.py:140-151)");
             return WT_ERR_NOT_INITED;
         }
-        if (int rc = upload_raw(M, e, (int64_t)a.vq_bins * 512, &M->embed)) return rc;
+        // num_quantizers > 1 (residual codebooks the checkpoint holds beside the first): encode_infer uses layer 0 only
+        // (vq.py:137 forces n_q = 1), codes_to_features sums the rows of the first K <= num_quantizers codebooks of the
+        // concatenated table (pretrained.py:230-237).  The table is stored concatenated; layer 0 comes first, so everything that
+        // addresses "the codebook" (VQ distances, its S32 copy, the encode plan's gather) is unchanged
+        std::vector<float> all((size_t)a.num_quantizers * a.vq_bins * 512);
+        std::memcpy(all.data(), e, (size_t)a.vq_bins * 512 * sizeof(float));
+        for (int q = 1; q < a.num_quantizers; ++q) {
+            const std::string pq = "feature_extractor.encodec.quantizer.vq.layers." + std::to_string(q) + "._codebook.";
+            const float* eq = tm.get(pq + "embed", (int64_t)a.vq_bins * 512);
+            if (!eq) return WT_ERR_MISSING_TENSOR;
+            std::memcpy(all.data() + (size_t)q * a.vq_bins * 512, eq, (size_t)a.vq_bins * 512 * sizeof(float));
+        }
+        if (int rc = upload(M, all, &M->embed)) return rc;
         std::vector<float> ee(a.vq_bins);
         for (int n = 0; n < a.vq_bins; ++n) {   // embed.pow(2).sum(0)
             float s = 0.f;
@@ -786,7 +798,7 @@ static int validate_imported(const wt_model* M) {
                (!l.Wp || fits(l.Wp, (size_t)3 * 32 * 4 * 16 * 2 * 64 * 16));
     };
     const int nf = 32, H = 512, D = a.dim, I = a.intermediate_dim;
-    if (a.n_ratios < 1 || a.n_ratios > 8 || a.num_quantizers != 1 || a.input_channels != 512 || D % 256 || I % 32 || a.num_layers < 1 || a.num_layers > 32 ||
+    if (a.n_ratios < 1 || a.n_ratios > 8 || a.num_quantizers < 1 || a.num_quantizers > 32 || a.input_channels != 512 || D % 256 || I % 32 || a.num_layers < 1 || a.num_layers > 32 ||
         a.adanorm_num_embeddings < 1 || a.vq_bins < 1 || a.n_fft < 4 || a.hop_length < 1) return bad("the architecture itself");
     int hop = 1;
     for (int i = 0; i < a.n_ratios; ++i) { if (a.ratios[i] < 1 || a.ratios[i] > 64) return bad("a ratio"); hop *= a.ratios[i]; }
@@ -803,7 +815,7 @@ static int validate_imported(const wt_model* M) {
         mult *= 2;
     }
     if (mult * nf != H || !lstm_ok(M->enc_lstm, H) || !conv_ok(M->enc_final, 512, H, 7)) return bad("the encoder tail");
-    if (!fits(M->embed, (size_t)a.vq_bins * 512 * 4) || !fits(M->ee, (size_t)a.vq_bins * 4)) return bad("the codebook");
+    if (!fits(M->embed, (size_t)a.num_quantizers * a.vq_bins * 512 * 4) || !fits(M->ee, (size_t)a.vq_bins * 4)) return bad("the codebook");
     if (!conv_ok(M->bb_embed, D, 512, 7)) return bad("backbone.embed");
     for (const PosRes& r : M->res)
         if (!fits(r.n1w, D * 4) || !fits(r.n1b, D * 4) || !fits(r.n2w, D * 4) || !fits(r.n2b, D * 4) || !conv_ok(r.c1, D, D, 3) || !conv_ok(r.c2, D, D, 3)) return bad("a pos_net block");

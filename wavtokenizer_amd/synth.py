@@ -139,6 +139,12 @@ def make_state_dict(arch: ArchConfig, seed: int = 0, with_seanet_decoder: bool =
     sd[VQ + "inited"] = np.ones((1,), np.float32)
     sd[VQ + "cluster_size"] = np.ones((arch.vq_bins,), np.float32)
     sd[VQ + "embed_avg"] = sd[VQ + "embed"].copy()
+    for q in range(1, arch.num_quantizers):        # further codebooks of a checkpoint with num_quantizers > 1 (codes_to_features sums them)
+        vq = VQ.replace("layers.0.", f"layers.{q}.")
+        sd[vq + "embed"] = normal(vq + "embed", (arch.vq_bins, H), 0.6 / (q + 1), seed)
+        sd[vq + "inited"] = np.ones((1,), np.float32)
+        sd[vq + "cluster_size"] = np.ones((arch.vq_bins,), np.float32)
+        sd[vq + "embed_avg"] = sd[vq + "embed"].copy()
 
     if with_seanet_decoder:
         for kind, prefix, a, b, k in seanet_decoder_specs(arch):
