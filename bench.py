@@ -472,7 +472,11 @@ def main():
                     hp.step()
                 hp.drain()
                 blk.append(1e3 * (time.perf_counter() - t0) / args.steps)
-            h2d_ms, d2h_ms = hp.copy_times_ms(8)     # the copy legs on a side stream while the lanes keep computing
+            def busy():
+                f_, _c = model.encode_infer(wav, bandwidth_id=bw)
+                model.decode(f_, bandwidth_id=bw)
+            h2d_ms, d2h_ms = hp.copy_times_ms(8, busy)     # the copy legs on a side stream beside a resident-input round trip
+            torch.cuda.synchronize()
             model.check_status()
             ms_hp = statistics.median(blk)
             resident = line["ms_per_step"]
@@ -550,9 +554,15 @@ def main():
             e1.synchronize()
             lat.append(e0.elapsed_time(e1))
         L30 = arch.frames(30 * SAMPLE_RATE)
+        r30b = Runner(model, wav30, bw, None, 1, 0, False, args.backend, lanes=2)      # the headline's schedule on this shape
+        r30b.step(); r30b.step(); r30b.drain()
+        blk2, _ = run_blocks(r30b, 6, 2, 3)
+        ms30_2 = statistics.median(1e3 * b / 6 for b in blk2)
+        del r30b
         other["hop600_32x30s"] = {
             "baseline_config": "configs[4] per-GPU share: WavTokenizer-large-600 architecture, 32 clips x 30 s",
             "ms_per_step": round(ms30, 3), "audio_s_per_s": round(32 * 30 / (ms30 * 1e-3), 1),
+            "ms_per_step_two_lanes": round(ms30_2, 3), "audio_s_per_s_two_lanes": round(32 * 30 / (ms30_2 * 1e-3), 1),
             "codes_per_sec": round(32 * L30 / (ms30 * 1e-3), 1), "p50_encode_infer_ms": round(statistics.median(lat), 3),
             "end_to_end_tflops": round(gflop_per_clip("hop600", arch, 30) * 32 * 1e9 / (ms30 * 1e-3) / 1e12, 2),
             "steps": 5, "blocks": 3}
@@ -586,6 +596,7 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -154,4 +154,7 @@ def test_host_pipeline_matches_the_resident_round_trip():
         assert g.dtype == np.int16 and np.array_equal(g, w), i
     h2d, d2h = hp.copy_times_ms(2)
     assert h2d > 0 and d2h > 0
+    wdev = torch.from_numpy(synth.make_clips(B, T, seed=1)).cuda()
+    h2d, d2h = hp.copy_times_ms(2, lambda: m.decode(m.encode_infer(wdev, bandwidth_id=bw)[0], bandwidth_id=bw))
+    assert h2d > 0 and d2h > 0
     m.check_status()

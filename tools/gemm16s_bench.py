@@ -3,6 +3,9 @@
 and per-kernel time.  Run under `rocprofv3 --kernel-trace --output-format csv -d <dir> -- python3 tools/gemm16s_bench.py
 <manifest.json>`; then `python3 tools/gemm16s_bench.py --summarize <manifest.json> <dir>` pairs the trace's GEMM
 dispatches with the calls listed in the manifest (the call order is the dispatch order)."""
+# the WT_* switches these measurements flip exist in the LAB build only (the product library reads no environment variable)
+import os as _os
+_os.environ.setdefault("WAVTOK_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tools", "lib", "libwavtok_hip_lab.so"))
 import csv, ctypes, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the implicit-GEMM kernel through wt_sconv1d (k=1 -> plain GEMM).
 Usage (GPU box): WT_GEMM_TILE=<n> python tools/gemm_bench.py"""
+# the WT_* switches these measurements flip exist in the LAB build only (the product library reads no environment variable)
+import os as _os
+_os.environ.setdefault("WAVTOK_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tools", "lib", "libwavtok_hip_lab.so"))
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,4 +1,6 @@
 #!/bin/bash
+# the WT_* switches exist in the LAB build only
+export WAVTOK_HIP_LIB=${WAVTOK_HIP_LIB:-$(cd "$(dirname "$0")/.." && pwd)/tools/lib/libwavtok_hip_lab.so}
 # FETCH_SIZE of the two ConvNeXt GEMM shapes for several scheduling group sizes (run on the GPU box)
 cd /tmp && export TMPDIR=/tmp
 for gm in 1 2 4 8 16 64; do

@@ -1,4 +1,6 @@
 #!/bin/bash
+# the WT_* switches exist in the LAB build only
+export WAVTOK_HIP_LIB=${WAVTOK_HIP_LIB:-$(cd "$(dirname "$0")/.." && pwd)/tools/lib/libwavtok_hip_lab.so}
 # tile-order sweep for gemm16s: WT_GEMM16S_GM x WT_GEMM16S_GN over the bench step (all GEMM launches take the same setting)
 run() { python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-other-configs --repeats 1 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['ms_per_step'], d['roofline']['avg_launch_ms'])"; }
 run default

@@ -1,4 +1,6 @@
 #!/bin/bash
+# the WT_* switches exist in the LAB build only
+export WAVTOK_HIP_LIB=${WAVTOK_HIP_LIB:-$(cd "$(dirname "$0")/.." && pwd)/tools/lib/libwavtok_hip_lab.so}
 # HBM-side read traffic (FETCH_SIZE) of the ConvNeXt GEMMs per tile order: WT_GEMM16S_GM x WT_GEMM16S_GN, one rocprofv3 --pmc pass each;
 # then the launch time of pwconv1 / pwconv2 per order in the GEMM lab.  Output: gpurun_out/gmn_traffic.txt
 cd /tmp && export TMPDIR=/tmp

@@ -1,5 +1,8 @@
 """Time the encoder's SLSTM alone (WT_PLAN_UNIT_LSTM: input projection + recurrence) at B x L; env WT_LSTM_GROUPS=1 = one clip group.
     python tools/lstm_time.py [B] [L]"""
+# the WT_* switches these measurements flip exist in the LAB build only (the product library reads no environment variable)
+import os as _os
+_os.environ.setdefault("WAVTOK_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tools", "lib", "libwavtok_hip_lab.so"))
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,3 +1,6 @@
+# the WT_* switches these measurements flip exist in the LAB build only (the product library reads no environment variable)
+import os as _os
+_os.environ.setdefault("WAVTOK_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tools", "lib", "libwavtok_hip_lab.so"))
 import ctypes, os, sys
 os.environ["WT_LSTM_TRACE"] = "1"
 sys.path.insert(0, "/root/repo")

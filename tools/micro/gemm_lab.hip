@@ -1,7 +1,7 @@
 // Same-process A/B of gemm16s_kernel variants on the ConvNeXt pwconv shapes (no torch, no Python): the kernel source is
 // included with WT_GEMM16S_LAB (its product dispatcher is compiled out) and the compile-time experiment masks listed in
 // VARIANTS are instantiated side by side.  Build + run on the GPU box:
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DWT_GEMM16S_LAB -o gpurun_out/gemm_lab tools/micro/gemm_lab.hip && gpurun_out/gemm_lab
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DWT_GEMM16S_LAB -DWT_LAB -o gpurun_out/gemm_lab tools/micro/gemm_lab.hip && gpurun_out/gemm_lab
 // Rounds are interleaved (variant 0, 1, 2, ..., 0, 1, ...) and the median launch time per variant is printed together with
 // the largest difference of its output from variant 0's (identical arithmetic unless the mask changes it).
 #include "../../wavtokenizer_amd/csrc/gemm16s.hip"

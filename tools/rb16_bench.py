@@ -3,6 +3,9 @@ under the WT_RB16_DBG ablation masks (1 no tile fill, 2 no resblock MFMAs, 4 no 
 
     python tools/rb16_bench.py [r] [dbg masks ...]        r = 4 / 2: stage 1 (hop-600 / hop-320); r = 0: the stage-2 resblock
 """
+# the WT_* switches these measurements flip exist in the LAB build only (the product library reads no environment variable)
+import os as _os
+_os.environ.setdefault("WAVTOK_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tools", "lib", "libwavtok_hip_lab.so"))
 import os
 import subprocess
 import sys

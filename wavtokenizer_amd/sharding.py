@@ -270,14 +270,22 @@ class HostPipeline:
         for s in self.s_lane:
             s.synchronize()
 
-    def copy_times_ms(self, steps: int = 8):
-        """(h2d ms, d2h ms) of one step's copies, measured on a side stream WHILE the lanes run `steps` more steps (median)."""
+    def copy_times_ms(self, steps: int = 8, busy=None):
+        """(h2d ms, d2h ms) of one step's copies, measured on a side stream beside compute (median of `steps`).  `busy()`, when
+        given, enqueues one resident-input round trip on the caller's stream per measurement: the copies are then timed beside
+        the codec's kernels but with the copy engines to themselves.  Without it the lanes' own steps run meanwhile - and
+        their copies share the engines' queues with the timed ones in submission order, a lane's H2D waiting (in stream order)
+        for that lane's previous step: the timed copy then reads as the wait in front of it (9 ms for a 0.34 ms copy)."""
+        self.drain()
         side = torch.cuda.Stream(device=self.dev)
         d_in = torch.empty_like(self.d_in[0])
         h_out = torch.empty_like(self.h_out[0]).pin_memory()
         h2d, d2h = [], []
         for _ in range(steps):
-            self.step()
+            if busy is not None:
+                busy()
+            else:
+                self.step()
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             with torch.cuda.stream(side):
                 ev[0].record()
