@@ -261,6 +261,28 @@ __global__ __launch_bounds__(ROWS / FPW * 64, DOWN ? 2 : 1) void resblock16_kern
         for (int e = tid; e < 2 * XR::bytes / 16; e += NT)         // xe rows ROWS, ROWS + 1: zero, never written again
             *reinterpret_cast<f32x4*>(xe + ROWS * XR::bytes + e * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // FOLD: the shortcut conv (1x1, seanet.py:62) of a block whose input IS the first conv's output is linear in the same seven
+    // samples: shortcut(x)[n][f] = sum_k (Ws . E0)[n][k] w[f + k - 3] + (Ws . b0)[n].  Its 32 x 8 matrix is this lane's second A
+    // fragment (formed in double, split like e0), and the block's output accumulators START from that product instead of
+    // reading a raw copy of x back from LDS: the raw split of x, its two 8-byte stores per 4 channels and the shortcut's two K
+    // steps (fragment reads + 6 MFMAs) are gone (r03: stage 1 is vector-issue bound, 27 % of its LDS cycles conflicts from
+    // exactly those stores)
+    f16x8 esh = {0, 0, 0, 0, 0, 0, 0, 0}, esl = esh;
+    if (FOLD) {
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if ((lane >> 5) == 0) {
+            double acc[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
+            for (int c = 0; c < C; ++c) {
+                const double wsc = (double)a.Ws[(long)(lane & 31) * C + c];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) acc[j] += wsc * (double)a.e0_w[j * C + c];
+                acc[7] += wsc * (double)a.e0_b[c];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (float)acc[j];
+        }
+        rb16_split8(v, esh, esl, wmax);
+    }
     // the reflect-padded waveform (conv.py:79-96) at padded position p of clip b; zero outside (clips shorter than the pad)
     auto wav_pad = [&](int b, int p) -> float {
         p = p < 0 ? -p : p;
@@ -343,7 +365,6 @@ __global__ __launch_bounds__(ROWS / FPW * 64, DOWN ? 2 : 1) void resblock16_kern
             // lane: row r, channels 8 g + 4 fh .. + 3.  Raw split -> xr row r - 1 (row 0 has none: its lanes fill xr row ROWS - 1,
             // which only the dropped last MFMA column of the shortcut reads, so that it holds tile data, not stale bits),
             // elu split -> xe row r
-            const int xrow = r == 0 ? ROWS - 1 : r - 1;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = 8 * g + 4 * fh;
@@ -352,11 +373,9 @@ __global__ __launch_bounds__(ROWS / FPW * 64, DOWN ? 2 : 1) void resblock16_kern
                 for (int i = 0; i < 4; ++i) x4[i] = xm[4 * g + i] + xc[4 * g + i] * LO_SCALE;
                 const f32x4 e4 = (DBG && (a.dbg & 16)) ? x4 : elu_med3_x4(x4);
                 f16x4 hi, lo;
-                rb16_split4(x4, hi, lo, amax);
-                *reinterpret_cast<f16x4*>(xr + xr_off(xrow, n & ~7, 0) + (n & 7) * 2) = hi;
-                *reinterpret_cast<f16x4*>(xr + xr_off(xrow, n & ~7, 1) + (n & 7) * 2) = lo;
-                float unused = 0.f;              // |elu(x)| <= |x|
-                rb16_split4(e4, hi, lo, unused);
+                // (no raw copy of x: the shortcut is folded into the first conv, see esh; elu(x) > -1, so its split tracks
+                // every magnitude that could leave the f16 range)
+                rb16_split4(e4, hi, lo, amax);
                 *reinterpret_cast<f16x4*>(xe + xe_off(r, n & ~7, 0) + (n & 7) * 2) = hi;
                 *reinterpret_cast<f16x4*>(xe + xe_off(r, n & ~7, 1) + (n & 7) * 2) = lo;
             }
@@ -573,9 +592,30 @@ __global__ __launch_bounds__(ROWS / FPW * 64, DOWN ? 2 : 1) void resblock16_kern
         for (int j = 0; j < TN2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { a2m[j][r] = 0.f; a2c[j][r] = 0.f; }
+        if constexpr (FOLD != 0) {
+            // shortcut(x) of output frame row0 + fl (= x row r + 1) straight from the tile's waveform window: B fragment = the
+            // frame's seven samples + 1 against (Ws . E0 | Ws . b0)
+            const int r = row0 + fl, f = t0 + r;
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            // wtile[i] = the reflect-padded waveform at padded position t0 - 4 + i, so frame f's tap j is wtile[r + 1 + j]
+            // (r + 7 <= ROWS + 6 < WAVN); an output frame is never a reflected one: rows beyond the clip are dropped by the store /
+            // never read by the down conv, and stay zero here
+            if (f >= 0 && f < a.T) {
+#pragma unroll
+                for (int j = 0; j < 7; ++j) v[j] = wtile[r + 1 + j];
+                v[7] = 1.f;
+            }
+            f16x8 sh, sl;
+            rb16_split8(v, sh, sl, amax);
+            if (!(dbg & 2)) {
+                a2m[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(esh, sh, a2m[0], 0, 0, 0);
+                a2c[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(esl, sh, a2c[0], 0, 0, 0);
+                a2c[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(esh, sl, a2c[0], 0, 0, 0);
+            }
+        }
         if (!(dbg & 2))
 #pragma unroll
-        for (int ks = 0; ks < L::K2 / 16; ++ks) {
+        for (int ks = 0; ks < (FOLD ? L::H / 16 : L::K2 / 16); ++ks) {
             f16x8 bh, bl;
             if (ks < L::H / 16) {
                 bh = *reinterpret_cast<const f16x8*>(he + HR::off(row0 + fl, ks * 16 + 8 * fh, 0));
