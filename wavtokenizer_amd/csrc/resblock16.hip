@@ -74,7 +74,8 @@ struct Rb16Layout {
     static constexpr int K1 = 3 * C, K2 = H + C;
     static constexpr int NX = ROWS + 2;
     static constexpr int off_xe = 0;                                 // elu(x), rows -1 .. ROWS
-    static constexpr int off_xr = off_xe + NX * C * 4;               // raw x, rows 0 .. ROWS-1
+    static constexpr int off_xr = off_xe + NX * C * 4;               // raw x, rows 0 .. ROWS-1 (FOLD: no raw copy exists - the shortcut goes
+                                                                     // through the first conv - and the rows only stage elu(y))
     static constexpr int off_he = off_xr + ROWS * C * 4;             // elu(hidden)
     static constexpr int off_w3 = off_he + ROWS * H * 4;             // [K1/16][hi, lo][N1 rows][32 B]
     static constexpr int off_w2 = off_w3 + (K1 / 16) * 2 * N1 * 32;  // [K2/16][hi, lo][C rows][32 B]
@@ -362,9 +363,7 @@ __global__ __launch_bounds__(ROWS / FPW * 64, DOWN ? 2 : 1) void resblock16_kern
             xm = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0h, bh, xm, 0, 0, 0);
             xc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0l, bh, xc, 0, 0, 0);
             xc = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0h, bl, xc, 0, 0, 0);
-            // lane: row r, channels 8 g + 4 fh .. + 3.  Raw split -> xr row r - 1 (row 0 has none: its lanes fill xr row ROWS - 1,
-            // which only the dropped last MFMA column of the shortcut reads, so that it holds tile data, not stale bits),
-            // elu split -> xe row r
+            // lane: row r, channels 8 g + 4 fh .. + 3: elu split -> xe row r (no raw copy: the shortcut is folded into esh)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = 8 * g + 4 * fh;
