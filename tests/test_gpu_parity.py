@@ -1475,3 +1475,33 @@ def test_codes_to_features_sums_several_codebooks():
     assert c3.shape == (1, 2, 15) and torch.equal(c3, c1) and torch.equal(f3, f1)
     assert torch.equal(m.codes_to_features(c3), f3)
     m.check_status()
+
+
+def test_range_overflow_in_the_encoder_puts_only_the_encoder_on_fp32(gpu_model):
+    """The encoder is one range site (WT_SITE_ENCODER).  A waveform 10^6 times full scale overflows the f16 range of its
+    first S32 tensor; the reference has no such limit.  With the default (strict for small batches) status the failing call
+    itself comes back correct from the fp32 chain - codes equal the oracle's by the margin rule - only bit 0 of the site mask
+    is set, and decode keeps running on the split-f16 kernels (its plans carry no fp32 site)."""
+    from wavtokenizer_amd import _capi, synth
+    from tests import parity_log
+    name, _m, sd = gpu_model
+    m = _fresh_model(name, sd)
+    orc = _oracle(name, sd)
+    wav = synth.make_clips(2, 12000, seed=77) * np.float32(1e6)
+    taps = {}
+    with torch.inference_mode():
+        fo, co = orc.encode_infer(torch.from_numpy(wav), BW, taps)
+        wo = orc.decode(fo, BW)
+    assert torch.isfinite(fo).all()
+    feats, codes = m.encode_infer(torch.from_numpy(wav).cuda(), bandwidth_id=BW)
+    assert m._fp32_sites == 1 << _capi.WT_SITE_ENCODER, bin(m._fp32_sites)
+    flips = check_codes(codes.cpu().numpy(), co.numpy(), taps["vq.margin"].numpy(), f"{name} x1e6")
+    out = m.decode(fo.cuda(), bandwidth_id=BW)
+    err = rel_l2(out.cpu().numpy(), wo.numpy())
+    assert err < WAV_REL_TOL, err
+    assert m._fp32_sites == 1 << _capi.WT_SITE_ENCODER                      # the decoder did not fall back
+    dkeys = [k for k in m._engine.plans if k[0] == _capi.WT_PLAN_DECODE]
+    assert dkeys and all(len(k) < 6 for k in dkeys), dkeys                   # decode plans without an fp32 site mask
+    with pytest.raises(_capi.WavTokError, match="fallback"):
+        m.check_status()
+    parity_log.record(f"range_encoder_site[{name}]", code_flips=flips, frames=int(co.numel()), wav_rel_l2=err)
