@@ -318,6 +318,22 @@ __global__ __launch_bounds__(ROWS / FPW * 64, DOWN ? 2 : 1) void resblock16_kern
     const int dbg = DBG ? a.dbg : 0;                 // timing experiments only (WT_RB16_DBG): 1 no tile fill, 2 no MFMA, 4 no store, 8 no down-conv taps, 16 no ELU
     constexpr float LO_SCALE = 1.f / 2048.f;
 
+    // C = 32: the conv3 / conv1 weight fragments of a lane do not depend on the tile: held in registers for the whole tile
+    // loop (3 taps x (hi, lo) + conv1's pair = 32 VGPRs) instead of eight ds_read_b128 per wave and tile
+    constexpr bool WREG = C == 32 && L::H == 16 && FPW == 32;
+    f16x8 w3rh[WREG ? 3 : 1], w3rl[WREG ? 3 : 1], w1rh = {0, 0, 0, 0, 0, 0, 0, 0}, w1rl = w1rh;
+    if constexpr (WREG) {
+        __syncthreads();                                 // the weight images are complete
+        const int m16 = lane & 15, q = lane >> 4;
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            w3rh[tap] = *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, 2 * tap + (q >> 1), 0, m16, q & 1, W3_SW));
+            w3rl[tap] = *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, 2 * tap + (q >> 1), 1, m16, q & 1, W3_SW));
+        }
+        w1rh = *reinterpret_cast<const f16x8*>(w2 + rb16_woff(C, 0, 0, fl, fh, W2_SW));
+        w1rl = *reinterpret_cast<const f16x8*>(w2 + rb16_woff(C, 0, 1, fl, fh, W2_SW));
+    }
+
     int b = (int)(blockIdx.x / (unsigned)tiles_per_clip), ti = (int)(blockIdx.x % (unsigned)tiles_per_clip);
     int wpar = 0;
     for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, wpar ^= 1) {
@@ -509,8 +525,8 @@ __global__ __launch_bounds__(ROWS / FPW * 64, DOWN ? 2 : 1) void resblock16_kern
             if (!(dbg & 2))
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap) {
-                const f16x8 wh = *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, 2 * tap + (q >> 1), 0, m16, q & 1, W3_SW));
-                const f16x8 wl = *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, 2 * tap + (q >> 1), 1, m16, q & 1, W3_SW));
+                const f16x8 wh = WREG ? w3rh[WREG ? tap : 0] : *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, 2 * tap + (q >> 1), 0, m16, q & 1, W3_SW));
+                const f16x8 wl = WREG ? w3rl[WREG ? tap : 0] : *reinterpret_cast<const f16x8*>(w3 + rb16_woff(L::N1, 2 * tap + (q >> 1), 1, m16, q & 1, W3_SW));
                 f16x8 bh[2], bl[2];
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
@@ -626,8 +642,9 @@ __global__ __launch_bounds__(ROWS / FPW * 64, DOWN ? 2 : 1) void resblock16_kern
             }
 #pragma unroll
             for (int j = 0; j < TN2; ++j) {
-                const f16x8 wh = *reinterpret_cast<const f16x8*>(w2 + rb16_woff(C, ks, 0, j * 32 + fl, fh, W2_SW));
-                const f16x8 wl = *reinterpret_cast<const f16x8*>(w2 + rb16_woff(C, ks, 1, j * 32 + fl, fh, W2_SW));
+                const bool reg = WREG && ks == 0 && j == 0;           // (compile-time after unrolling)
+                const f16x8 wh = reg ? w1rh : *reinterpret_cast<const f16x8*>(w2 + rb16_woff(C, ks, 0, j * 32 + fl, fh, W2_SW));
+                const f16x8 wl = reg ? w1rl : *reinterpret_cast<const f16x8*>(w2 + rb16_woff(C, ks, 1, j * 32 + fl, fh, W2_SW));
                 a2m[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, a2m[j], 0, 0, 0);
                 a2c[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, a2c[j], 0, 0, 0);
                 a2c[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, a2c[j], 0, 0, 0);
