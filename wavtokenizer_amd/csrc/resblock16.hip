@@ -279,6 +279,8 @@ __global__ __launch_bounds__(ROWS / FPW * 64, DOWN ? 2 : 1) void resblock16_kern
                 for (int j = 0; j < 7; ++j) acc[j] += wsc * (double)a.e0_w[j * C + c];
                 acc[7] += wsc * (double)a.e0_b[c];
             }
+            // ... and the block's output bias b1 + bs rides on the same constant-1 column: the output epilogue adds none
+            acc[7] += (double)a.b1[lane & 31] + (double)a.bs[lane & 31];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = (float)acc[j];
         }
@@ -662,7 +664,10 @@ __global__ __launch_bounds__(ROWS / FPW * 64, DOWN ? 2 : 1) void resblock16_kern
                     const int n = j * 32 + 8 * g + 4 * fh;
                     f32x4 v;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = a2m[j][4 * g + i] + a2c[j][4 * g + i] * LO_SCALE + bb[L::N1 + n + i];
+                    for (int i = 0; i < 4; ++i) {
+                        v[i] = a2m[j][4 * g + i] + a2c[j][4 * g + i] * LO_SCALE;
+                        if constexpr (FOLD == 0) v[i] += bb[L::N1 + n + i];       // (FOLD: b1 + bs came in through the folded shortcut's bias column)
+                    }
                     if ((DOWN || a.elu_out) && !(dbg & 16)) v = elu_med3_x4(v);
                     if (DOWN || a.out_s32) {                        // S32: chunk (n/32)*8 + n%32/8 holds hi, + 4 holds lo
                         f16x4 hi, lo;
