@@ -18,7 +18,7 @@ import sys
 
 
 def _one(pattern):
-    fs = sorted(glob.glob(pattern, recursive=True))
+    fs = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)      # the newest run (output directories are reused)
     if not fs:
         raise SystemExit(f"no file matches {pattern}")
     return fs[-1]
