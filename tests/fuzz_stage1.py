@@ -1,5 +1,6 @@
 """Random-shape check of the fused stage-1 kernel (wt_resblock_down) against the oracle: lengths around tile edges and clip
-ends, any remainder modulo the stride, small and odd batch sizes.  python tools/fuzz_stage1.py [cases per architecture]"""
+ends, any remainder modulo the stride, small and odd batch sizes.  (A script, not collected by pytest; it lives under tests/
+because it uses the oracle, which only tests/, smoke() and bench.py's cpu_baseline leg may import.)  python tests/fuzz_stage1.py [cases per architecture]"""
 import os
 import sys
 
